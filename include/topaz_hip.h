@@ -1,0 +1,151 @@
+/* libtopaz_hip.so -- C-ABI of the MI355X (gfx950) hot path of tbepler/topaz.
+ *
+ * The reference has no FFI layer: its boundary is the Python callable
+ *     model(x: Tensor[N,1,H,W]) -> Tensor[N,1,H,W]          (nn.Module.__call__)
+ * invoked from topaz/extract.py:249, topaz/model/utils.py:122, topaz/predict.py:26,
+ * topaz/denoise.py:293, plus the pure functions non_maximum_suppression
+ * (topaz/algorithms.py:25) / non_maximum_suppression_3d (:66) and Denoise.denoise
+ * (topaz/denoise.py:328) / Denoise3D.denoise (:340).  Each entry point below names the
+ * reference interface it replaces.  The Python package topaz_amd binds these with ctypes
+ * (topaz_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; tpz_last_error(ctx) gives the text.
+ *   - plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HBM of the
+ *     ctx's GPU); h_* are host pointers.  fp32 everywhere, tensors are dense, C-order
+ *     [C][D][H][W] (D omitted in 2-D), batch entries are processed one after another.
+ *   - one ctx per process/GPU; calls on a ctx are serialised on its HIP stream
+ *     (tpz_ctx_set_stream lets the caller supply e.g. torch's current stream).
+ *     Calls are asynchronous w.r.t. the host unless stated; tpz_ctx_sync waits.
+ *   - the library owns its workspaces (grow-only), the caller owns in/out buffers.
+ */
+#ifndef TOPAZ_HIP_H
+#define TOPAZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tpz_ctx tpz_ctx;
+typedef struct tpz_model tpz_model;
+
+/* ---- layer program: the manifest a model is loaded from ------------------------------
+ * A model is a list of ops over tensor "slots".  Slot 0 is the network input (1 channel);
+ * the dst slot of the last layer is the network output.  The host packer
+ * (topaz_amd/model/pack.py) emits this from a state_dict / unpickled module; it mirrors
+ * the module graphs of topaz/model/features/resnet.py:243-251,185-202,
+ * topaz/model/features/basic.py:98-111, topaz/model/classifier.py:64-66 and
+ * topaz/denoising/models.py:130-175,515-562.                                              */
+enum { TPZ_OP_CONV = 1, TPZ_OP_MAXPOOL2 = 2 };
+
+typedef struct tpz_layer {
+    int32_t op;        /* TPZ_OP_* */
+    int32_t dims;      /* 2 or 3 */
+    int32_t src;       /* input slot */
+    int32_t src2;      /* -1, or slot concatenated AFTER src on the channel axis; src is first
+                          nearest-upsampled to src2's size (F.interpolate(mode='nearest') + torch.cat,
+                          denoising/models.py:140-171) */
+    int32_t dst;       /* output slot */
+    int32_t cin;       /* total input channels (src [+ src2]) */
+    int32_t cout;
+    int32_t k;         /* cubic kernel size */
+    int32_t dil;       /* dilation (the "filled" stride->dilation rewrite, resnet.py:87-92,153-164) */
+    int32_t pad;       /* zero padding on every side */
+    float slope;       /* activation y = v > 0 ? v : slope*v : 0 = ReLU, 0.1 = LeakyReLU, 1 = none, else PReLU */
+    int64_t w_off;     /* offset (floats) of the [cout][cin][k(][k)][k] weights in the blob */
+    int64_t b_off;     /* offset of the [cout] bias, -1 = none */
+    int32_t res;       /* -1, or slot added before the activation (ResidA skip, resnet.py:185-202) */
+    int32_t res_crop;  /* the skip is centre-cropped by this many pixels per side */
+    int64_t post_scale_off; /* -1, or [cout] scale of the eval-BN affine applied AFTER the add (bn1) */
+    int64_t post_shift_off;
+    int32_t head;      /* 1: fuse a following 1x1 conv cout->1 (classifier.py:29,65); dst then has 1 channel */
+    int32_t reserved;
+    int64_t head_w_off;/* [cout] */
+    int64_t head_b_off;/* [1] */
+} tpz_layer;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* replaces topaz/cuda.py:16-32 set_device (no CPU fallback: errors are reported, never hidden) */
+int tpz_ctx_create(int device_id, tpz_ctx** out);
+void tpz_ctx_destroy(tpz_ctx* ctx);
+const char* tpz_last_error(tpz_ctx* ctx);            /* ctx may be NULL: last global error */
+int tpz_ctx_set_stream(tpz_ctx* ctx, void* hip_stream); /* NULL = the ctx's own stream */
+int tpz_ctx_sync(tpz_ctx* ctx);
+const char* tpz_version(void);
+
+/* ---- models -------------------------------------------------------------------------- */
+/* replaces topaz/model/factory.py:33-64 load_model + model.eval(); model.fill(); model.cuda()
+ * (extract.py:227-232) and topaz/denoising/models.py:581-625 load_model + .cuda() (denoise.py:248-262):
+ * weights are packed into MFMA fragment order and copied to the device; the model owns them. */
+int tpz_model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob,
+                   size_t n_floats, tpz_model** out);
+void tpz_model_free(tpz_model* m);
+
+/* replaces model(x) -- LinearClassifier.forward (classifier.py:48-66), UDenoiseNet.forward
+ * (denoising/models.py:130-175), UDenoiseNet3D.forward (:515-562).
+ * d_in [n][1][D][H][W] -> d_out [n][1][Do][Ho][Wo]; D = 1 for 2-D models. */
+int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out);
+/* output size of the model for a given input size */
+int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int* Wo);
+
+/* ---- denoising ----------------------------------------------------------------------- */
+/* replaces Denoise.denoise / denoise_patches / _denoise (topaz/denoise.py:274-332):
+ * patch grid range(0,H,patch) x range(0,W,patch), each crop [i-pad, i+patch+pad) clipped to the
+ * image is normalised by ITS OWN mean / unbiased std (torch.std), run through the net,
+ * un-normalised and its centre pasted.  patch <= 0 or patch+pad >= max(H,W): whole image. */
+int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out);
+/* replaces Denoise3D.denoise + PatchDataset (topaz/denoise.py:340-377,
+ * topaz/denoising/datasets.py:412-468): global mean / population std (numpy), zero-filled
+ * (patch+2*pad)^3 tiles normalised globally then per tile (unbiased), stitched.
+ * patch < 1: the whole volume goes through _denoise. */
+int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out);
+/* mean and std of n floats; unbiased != 0 -> divide by n-1 (torch.std), else by n (numpy.std)
+ * (topaz/denoise.py:283,343,388).  h_mean_std[2] on the host; synchronises. */
+int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std);
+/* y = x*scale + shift  (the (x-mu)/std and std*y+mu steps of topaz/denoise.py:389,414) */
+int tpz_affine(tpz_ctx* ctx, const float* d_x, size_t n, float scale, float shift, float* d_y);
+/* 1->1 channel 2-D filter with zero "same" padding: GaussianDenoise / InvGaussianFilter /
+ * AffineFilter.forward (topaz/filters.py:28-96).  h_w is the [k][k] kernel on the host. */
+int tpz_filter_2d(tpz_ctx* ctx, const float* d_in, int H, int W, const float* h_w, int k, float bias,
+                  float* d_out);
+
+/* ---- non-maximum suppression ----------------------------------------------------------- */
+/* replaces non_maximum_suppression(x, r, threshold) (topaz/algorithms.py:25-63), bit-identical
+ * to the greedy loop including the clip-to-W quirk (offsets past the right edge suppress
+ * column 0 of the next row).  Ties between equal scores are ordered by DESCENDING flat index
+ * (what a stable argsort reversed gives; numpy's default argsort leaves tie order undefined).
+ * Outputs (device): d_coords [cap][2] int32 (x, y), d_scores [cap] fp32, in descending score order.
+ * *h_n receives the number of picks found (may exceed cap: then only cap rows were written
+ * and the return code is non-zero).  Synchronises. */
+int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float threshold,
+               int32_t* d_coords, float* d_scores, int cap, int* h_n);
+/* replaces non_maximum_suppression_3d(x, r, scale, threshold) (topaz/algorithms.py:66-103):
+ * flat-index deltas, no clipping (they wrap across rows/planes); d_coords [cap][3] (x, y, z). */
+int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, float scale,
+               float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n);
+
+/* ---- single ops (unit tests and the host-side pipelines) --------------------------------- */
+/* one fused convolution: the op the layer program is made of.  h_w [cout][cin][k..], h_b [cout] or NULL.
+ * d_in2 / d_res / h_post_* may be NULL.  in is [cin1][D1][H1][W1]; when d_in2 != NULL it is
+ * nearest-upsampled to in2's [cin-cin1][D][H][W] and concatenated. */
+int tpz_conv(tpz_ctx* ctx, int dims, const float* d_in, int cin1, int D1, int H1, int W1, const float* d_in2,
+             int cin, int D, int H, int W, const float* h_w, const float* h_b, int cout, int k, int dil,
+             int pad, float slope, const float* d_res, int res_crop, const float* h_post_scale,
+             const float* h_post_shift, const float* h_head_w, float head_b, float* d_out);
+int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H, int W, float* d_out);
+
+/* ---- introspection / measurement --------------------------------------------------------- */
+/* time (ms, HIP events on the ctx stream) and launch count of the kernels of one class since
+ * the last reset.  cls: 0 = conv_mfma, 1 = conv_direct, 2 = elementwise, 3 = nms.
+ * Timing is only collected while enabled (it adds two event records per launch). */
+int tpz_prof_enable(tpz_ctx* ctx, int on);
+int tpz_prof_reset(tpz_ctx* ctx);
+int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPAZ_HIP_H */

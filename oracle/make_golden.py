@@ -1,0 +1,235 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Test infrastructure; runs only in the build container, where /root/reference (tbepler/topaz
+v0.3.18) is mounted.  Recipe:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference is imported with one stub (h5py, imported at module top by
+topaz/denoising/datasets.py:8 but unused on this path).  Nothing of the reference is copied:
+the fixtures hold seeded inputs, the reference's outputs, and -- for architectures whose
+pretrained blobs are missing -- the seeded weights that were loaded into the reference modules.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = os.environ.get('TOPAZ_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+_h5 = types.ModuleType('h5py')
+_h5.File = object
+sys.modules['h5py'] = _h5
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+META = dict(reference='tbepler/topaz 0.3.18', torch=torch.__version__, numpy=np.__version__)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, meta=np.asarray(repr(META)), **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def sd_arrays(model, prefix='sd:'):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+            m.running_mean.data = 0.1 * torch.randn(m.running_mean.shape, generator=g)
+            m.running_var.data = 1.0 + 0.2 * torch.rand(m.running_var.shape, generator=g)
+
+
+def image(seed, h, w):
+    return np.random.RandomState(seed).randn(h, w).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+def scoring():
+    from topaz.model.factory import load_model
+    from topaz.model.classifier import LinearClassifier
+    from topaz.model.features.resnet import ResNet8, ResNet16
+    from topaz.model.features.basic import BasicConv
+
+    def run(model, x):
+        model.eval()
+        if not getattr(model, '_golden_filled', False):
+            model.fill()                            # once, as extract.py:230 does (a second fill() compounds)
+            model._golden_filled = True
+        with torch.no_grad():                       # extract.py:249 path (run under no_grad)
+            return model(torch.from_numpy(x)[None, None])[0, 0].numpy()
+
+    for name in ('resnet8_u32', 'resnet16_u32'):
+        m = load_model(name)
+        xs = {'x0': image(1, 96, 96), 'x1': image(2, 160, 200)}
+        ys = {k.replace('x', 'y'): run(m, v) for k, v in xs.items()}
+        save(f'score_{name}', arch=np.asarray(name.split('_')[0]), **xs, **ys)
+
+    # seeded nets (random init of the reference's own constructors)
+    torch.manual_seed(7)
+    m = LinearClassifier(ResNet8(units=16, bn=True))
+    randomise_bn(m, 8)
+    x = image(3, 120, 136)
+    save('score_resnet8_bn_u16', arch=np.asarray('resnet8'), x0=x, y0=run(m, x), **sd_arrays(m))
+
+    torch.manual_seed(9)
+    m = LinearClassifier(ResNet16(units=16, bn=False))
+    x = image(4, 100, 112)
+    save('score_resnet16_u16', arch=np.asarray('resnet16'), x0=x, y0=run(m, x), **sd_arrays(m))
+
+    torch.manual_seed(11)
+    m = LinearClassifier(BasicConv([7, 5, 5, 5, 5], 16, bn=True))      # factory.py:15-17 conv127
+    randomise_bn(m, 12)
+    for p in m.modules():
+        if isinstance(p, torch.nn.PReLU):
+            p.weight.data.uniform_(0.1, 0.4)
+    x = image(5, 140, 150)
+    save('score_conv127_bn_u16', arch=np.asarray('conv127'), x0=x, y0=run(m, x), **sd_arrays(m))
+
+    torch.manual_seed(13)
+    m = LinearClassifier(BasicConv([7, 5, 5], 32, bn=False))           # conv31, bias instead of BN
+    x = image(6, 64, 72)
+    save('score_conv31_u32', arch=np.asarray('conv31'), x0=x, y0=run(m, x), **sd_arrays(m))
+
+    # patched scoring (model/utils.py:110-193), float64 result
+    from topaz.model.utils import predict_in_patches
+    m = load_model('resnet8_u32')
+    m.eval()
+    m.fill()
+    x = image(14, 200, 260)
+    y = predict_in_patches(m, torch.from_numpy(x)[None, None], 96 + 2 * (m.width // 2))
+    save('score_patched_resnet8_u32', x0=x, y0=y[0, 0], patch=np.asarray(96))
+
+
+def nms():
+    from topaz.algorithms import non_maximum_suppression, non_maximum_suppression_3d
+    from topaz.model.factory import load_model
+    cases = {}
+
+    def add2(name, x, r, thr):
+        s, c = non_maximum_suppression(x, r, threshold=thr)
+        cases[name + ':x'] = x
+        cases[name + ':r'] = np.asarray(r)
+        cases[name + ':thr'] = np.asarray(thr, dtype=np.float64)
+        cases[name + ':scores'] = s
+        cases[name + ':coords'] = c
+
+    def add3(name, x, r, scale, thr):
+        s, c = non_maximum_suppression_3d(x, r, scale=scale, threshold=thr)
+        cases[name + ':x'] = x
+        cases[name + ':r'] = np.asarray(r)
+        cases[name + ':scale'] = np.asarray(scale, dtype=np.float64)
+        cases[name + ':thr'] = np.asarray(thr, dtype=np.float64)
+        cases[name + ':scores'] = s
+        cases[name + ':coords'] = c
+
+    rs = np.random.RandomState(21)
+    add2('rand_r3', rs.randn(64, 80).astype(np.float32), 3, -0.5)
+    add2('rand_r1', rs.randn(40, 33).astype(np.float32), 1, 0.0)
+    add2('rand_r0', rs.randn(9, 11).astype(np.float32), 0, 0.5)
+    add2('rand_noinf', rs.randn(24, 24).astype(np.float32), 4, -np.inf)
+    # right-edge wrap: the peak at (y=10, x=W-1) suppresses (y=11, x=0) with r=3 ...
+    x = np.full((20, 30), -10, dtype=np.float32)
+    x[10, 29] = 5.0
+    x[11, 0] = 4.0
+    x[12, 0] = 3.5
+    x[14, 0] = 3.0
+    add2('wrap_edge', x, 3, -6.0)
+    # ... but a peak at x = W-6 does not
+    x = np.full((20, 30), -10, dtype=np.float32)
+    x[10, 24] = 5.0
+    x[11, 0] = 4.0
+    add2('wrap_far', x, 3, -6.0)
+    # strict threshold: -5.9 kept at t=-6, -6.0 dropped
+    x = np.full((8, 8), -7, dtype=np.float32)
+    x[2, 2] = -5.9
+    x[5, 5] = -6.0
+    add2('thr_strict', x, 1, -6.0)
+    # bottom/right corner and low-side clipping
+    x = rs.randn(16, 12).astype(np.float32)
+    x[15, 11] = 9
+    x[0, 0] = 8
+    x[0, 11] = 7
+    x[15, 0] = 6
+    add2('corners', x, 5, -1.0)
+    # tiny image, radius larger than the image
+    add2('tiny', rs.randn(3, 4).astype(np.float32), 6, -5.0)
+    # real logit map, several radii
+    m = load_model('resnet8_u32')
+    m.eval()
+    m.fill()
+    with torch.no_grad():
+        logit = m(torch.from_numpy(image(2, 160, 200))[None, None])[0, 0].numpy()
+    for r in (1, 3, 8, 14):
+        add2(f'logits_r{r}', logit, r, -6.0)
+    # 3-D
+    add3('vol_r2', rs.randn(12, 20, 16).astype(np.float32), 2, 1.0, 0.0)
+    add3('vol_r2_s15', rs.randn(10, 12, 14).astype(np.float32), 2, 1.5, -0.3)
+    v = np.full((6, 8, 10), -10, dtype=np.float32)
+    v[2, 2, 9] = 5.0
+    v[2, 3, 0] = 4.0          # wraps: flat-index delta suppresses across the row
+    v[4, 7, 9] = 3.0
+    v[5, 0, 0] = 2.5
+    add3('vol_wrap', v, 1, 1.0, -6.0)
+    save('nms_cases', **cases)
+
+
+def denoise2d():
+    from topaz.denoise import Denoise, denoise_image
+    from topaz.filters import GaussianDenoise
+    out = {}
+    x = image(31, 150, 140) * 3.0 + 10.0
+    out['x'] = x
+    for name in ('unet-v0.2.1', 'unet-small', 'fcnn', 'affine'):
+        d = Denoise(name)
+        out[f'{name}:whole'] = d.denoise(x, patch_size=-1)
+        out[f'{name}:p64_24'] = d.denoise(x, patch_size=64, padding=24)
+    d = Denoise('unet-v0.2.1')
+    out['image:unet-v0.2.1:p96_16'] = denoise_image(x.copy(), [d], patch_size=96, padding=16)
+    out['image:unet-v0.2.1:norm'] = denoise_image(x.copy(), [d], patch_size=-1, padding=0, normalize=True)
+    g = GaussianDenoise(1.2)
+    out['image:unet-small:gaus1.2'] = denoise_image(x.copy(), [Denoise('unet-small')], gaus=g, patch_size=-1)
+    out['gaus1.2:apply'] = g.apply(x)
+    out['image:affine:cutoff'] = denoise_image(x.copy(), [Denoise('affine')], cutoff=1.5, patch_size=-1)
+    # seeded v0.2.2 architecture (blob missing): UDenoiseNet(base 11, top 5)
+    from topaz.denoising.models import UDenoiseNet
+    torch.manual_seed(41)
+    net = UDenoiseNet(nf=16, base_width=11, top_width=5)
+    dn = Denoise.__new__(Denoise)
+    dn.model, dn.device, dn.dims, dn.use_cuda = net.eval(), torch.device('cpu'), 2, False
+    x2 = image(32, 110, 121)
+    save('denoise2d_unet_b11t5_nf16', x=x2, whole=dn.denoise(x2, patch_size=-1), p48_20=dn.denoise(x2, 48, 20),
+         **sd_arrays(net))
+    save('denoise2d_pretrained', **out)
+
+
+def denoise3d():
+    from topaz.denoise import Denoise3D
+    from topaz.denoising.models import UDenoiseNet3D
+    torch.manual_seed(51)
+    net = UDenoiseNet3D(nf=8, base_width=7)
+    dn = Denoise3D.__new__(Denoise3D)
+    dn.model, dn.device, dn.dims, dn.use_cuda = net.eval(), torch.device('cpu'), 3, False
+    tomo = (np.random.RandomState(52).randn(40, 50, 60) * 2.0 + 1.0).astype(np.float32)
+    y = dn.denoise(tomo, patch_size=32, padding=16, verbose=False)
+    small = tomo[:33, :34, :36].copy()
+    y_whole = dn.denoise(small, patch_size=-1, verbose=False)
+    save('denoise3d_unet3d_nf8', tomo=tomo, p32_16=y, small=small, small_whole=y_whole, **sd_arrays(net))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d']
+    torch.set_num_threads(8)
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,229 @@
+"""Oracle (test infrastructure): CPU restatement of the reference's filled scoring networks.
+
+Follows topaz/model/features/resnet.py (BasicConv :50-105, ResidA :108-204, ResNet.fill/forward
+:227-251, ResNet8 :280-306, ResNet16 :309-339), topaz/model/features/basic.py (BasicConv :12-111),
+topaz/model/classifier.py (LinearClassifier :14-66) and topaz/model/utils.py insize_from_outsize
+(:39-68).  The networks are described as plain data (a list of module specs), `fill` performs the
+reference's stride -> dilation rewrite on that data, and `forward` evaluates it with torch-CPU
+functional ops on a state_dict.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------
+# architecture specs (unfilled), mirroring make_modules of the reference
+# ---------------------------------------------------------------------------------------------
+def _basic(k, stride=1, dilation=1):
+    return {'type': 'basic', 'k': k, 'stride': stride, 'og_dilation': dilation, 'dilation': dilation}
+
+
+def _resid(dilation=1, stride=1):
+    # ResidA: conv0 3x3 (dil 1), conv1 3x3 (dil `dilation`, stride `stride`); resnet.py:129-143
+    return {'type': 'resid', 'k': 2 * dilation + 3, 'stride': stride, 'conv0_dil': 1, 'conv1_dil': dilation,
+            'dilation': 1}
+
+
+def resnet8_spec() -> List[dict]:
+    # resnet.py:293-302 with pooling=None -> stride = 2
+    s = 2
+    return [_basic(7, stride=s), _resid(dilation=2), _resid(dilation=2, stride=s), _resid(dilation=2), _basic(5)]
+
+
+def resnet16_spec() -> List[dict]:
+    # resnet.py:322-335 with pooling=None -> stride = 2
+    s = 2
+    return [_basic(7), _resid(stride=s), _resid(), _resid(), _resid(), _resid(stride=s), _resid(), _resid(), _basic(5)]
+
+
+def width_of(spec: List[dict]) -> int:
+    """receptive field of the unfilled stack: insize_from_outsize(modules, 1) (model/utils.py:39-68).
+    The module-level attributes it reads are kernel_size / stride / dilation / padding of BasicConv
+    (resnet.py:73-78) and ResidA (resnet.py:138-141: kernel_size = 2*dilation+3, dilation = 1)."""
+    out = 1
+    for m in spec[::-1]:
+        dil = m['dilation'] if m['type'] == 'basic' else 1
+        out = (out - 1) * m['stride'] + 1 + (m['k'] - 1) * dil
+    return out
+
+
+def fill(spec: List[dict]) -> int:
+    """ResNet.fill (resnet.py:227-232): thread the cumulative stride through the modules, turning
+    strides into dilations (BasicConv.fill :87-92, ResidA.fill :153-164).  Returns the total stride."""
+    stride = 1
+    for m in spec:
+        if m['type'] == 'basic':
+            m['conv_dil'] = m['og_dilation'] * stride
+        else:
+            m['conv0_fdil'] = stride
+            m['conv1_fdil'] = m['conv1_dil'] * stride
+        stride *= m['stride']
+    return stride
+
+
+def _bn(y, sd, prefix):
+    if prefix + '.weight' not in sd:
+        return y
+    return F.batch_norm(y, sd[prefix + '.running_mean'], sd[prefix + '.running_var'], sd[prefix + '.weight'],
+                        sd[prefix + '.bias'], training=False, eps=1e-5)
+
+
+def resnet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: List[dict], prefix='features.features.',
+                   head=True) -> torch.Tensor:
+    """Filled forward of LinearClassifier(ResNetN): x [N,1,H,W] -> logits [N,1,H,W].
+    resnet.py:243-251 (pad by width//2, Sequential), :101-105 (BasicConv), :185-202 (ResidA),
+    classifier.py:64-66 (1x1 head)."""
+    p = width_of(spec) // 2
+    h = F.pad(x, (p, p, p, p))
+    for i, m in enumerate(spec):
+        pre = f'{prefix}{i}.'
+        if m['type'] == 'basic':
+            h = F.conv2d(h, sd[pre + 'conv.weight'], sd.get(pre + 'conv.bias'), dilation=m['conv_dil'])
+            h = _bn(h, sd, pre + 'bn')
+            h = F.relu(h)
+        else:
+            d0, d1 = m['conv0_fdil'], m['conv1_fdil']
+            t = F.conv2d(h, sd[pre + 'conv0.weight'], sd.get(pre + 'conv0.bias'), dilation=d0)
+            t = _bn(t, sd, pre + 'bn0')
+            t = F.relu(t)
+            y = F.conv2d(t, sd[pre + 'conv1.weight'], sd.get(pre + 'conv1.bias'), dilation=d1)
+            edge = d0 + d1
+            xs = h[:, :, edge:-edge, edge:-edge]
+            if pre + 'proj.weight' in sd:
+                xs = F.conv2d(xs, sd[pre + 'proj.weight'])
+            y = y + xs
+            y = _bn(y, sd, pre + 'bn1')      # bn1 comes AFTER the add (resnet.py:199-201)
+            h = F.relu(y)
+    if head:
+        h = F.conv2d(h, sd['classifier.weight'], sd['classifier.bias'])
+    return h
+
+
+def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5, 5, 5, 5),
+                      prefix='features.features.', head=True) -> torch.Tensor:
+    """Filled forward of LinearClassifier(basic.BasicConv(sizes, units)) -- conv127/63/31
+    (basic.py:12-111, factory.py:15-25).  Every conv but the last has stride 2 (no pooling), so
+    fill() gives dilations 1,2,4,... (basic.py:81-89); pad = width//2 with width from the strided
+    stack (basic.py:72,105-109).  Module indices advance conv[,bn],act (basic.py:46-69)."""
+    has_bn = any(k.endswith('running_mean') for k in sd)
+    strides = [2] * (len(sizes) - 1) + [1]
+    width = 1
+    for k, s in zip(sizes[::-1], strides[::-1]):
+        width = (width - 1) * s + 1 + (k - 1)
+    p = width // 2
+    h = F.pad(x, (p, p, p, p))
+    idx, dil = 0, 1
+    for k, s in zip(sizes, strides):
+        h = F.conv2d(h, sd[f'{prefix}{idx}.weight'], sd.get(f'{prefix}{idx}.bias'), dilation=dil)
+        idx += 1
+        if has_bn:
+            h = _bn(h, sd, f'{prefix}{idx}')
+            idx += 1
+        h = F.prelu(h, sd[f'{prefix}{idx}.weight'])
+        idx += 1
+        dil *= s
+    if head:
+        h = F.conv2d(h, sd['classifier.weight'], sd['classifier.bias'])
+    return h
+
+
+ARCH_SPECS = {'resnet8': resnet8_spec, 'resnet16': resnet16_spec}
+BASIC_SIZES = {'conv127': (7, 5, 5, 5, 5), 'conv63': (7, 5, 5, 5), 'conv31': (7, 5, 5)}
+
+
+def to_torch_sd(sd) -> Dict[str, torch.Tensor]:
+    return OrderedDict((k, torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v) for k, v in sd.items())
+
+
+@torch.no_grad()
+def score(arch: str, sd, x: np.ndarray, num_threads: int = 0) -> np.ndarray:
+    """logits of one [H,W] image with the filled network `arch` (what extract.py:247-249 computes)."""
+    if num_threads:
+        torch.set_num_threads(num_threads)
+    sd = to_torch_sd(sd)
+    xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None, None]
+    if arch in ARCH_SPECS:
+        spec = ARCH_SPECS[arch]()
+        fill(spec)
+        y = resnet_forward(xt, sd, spec)
+    elif arch in BASIC_SIZES:
+        y = basicconv_forward(xt, sd, BASIC_SIZES[arch])
+    else:
+        raise ValueError(arch)
+    return y[0, 0].numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded synthetic weights for architectures whose pretrained blobs are absent
+# ---------------------------------------------------------------------------------------------
+def synthetic_resnet_sd(arch: str, units: int, seed: int, bn: bool = False) -> 'OrderedDict[str, np.ndarray]':
+    """He-style random weights with the key layout of LinearClassifier(ResNet8/16(units, bn))."""
+    rs = np.random.RandomState(seed)
+    spec = ARCH_SPECS[arch]()
+    sd = OrderedDict()
+
+    def conv(name, co, ci, k, bias):
+        sd[name + '.weight'] = (rs.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        if bias:
+            sd[name + '.bias'] = (rs.randn(co) * 0.1).astype(np.float32)
+
+    def bnorm(name, c):
+        sd[name + '.weight'] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.bias'] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.running_mean'] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.running_var'] = (1.0 + 0.2 * rs.rand(c)).astype(np.float32)
+
+    u = [units, 2 * units, 4 * units]
+    if arch == 'resnet8':
+        chans = [(1, u[0]), (u[0], u[0]), (u[0], u[1]), (u[1], u[1]), (u[1], u[2])]
+    else:
+        chans = [(1, u[0])] + [(u[0], u[0])] * 4 + [(u[0], u[1])] + [(u[1], u[1])] * 2 + [(u[1], u[2])]
+    for i, (m, (ci, co)) in enumerate(zip(spec, chans)):
+        pre = f'features.features.{i}.'
+        if m['type'] == 'basic':
+            conv(pre + 'conv', co, ci, m['k'], not bn)
+            if bn:
+                bnorm(pre + 'bn', co)
+        else:
+            if ci != co:
+                conv(pre + 'proj', co, ci, 1, False)
+            conv(pre + 'conv0', ci, ci, 3, not bn)
+            if bn:
+                bnorm(pre + 'bn0', ci)
+            conv(pre + 'conv1', co, ci, 3, not bn)
+            if bn:
+                bnorm(pre + 'bn1', co)
+    sd['classifier.weight'] = (rs.randn(1, u[2], 1, 1) * np.sqrt(1.0 / u[2])).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([-2.0], dtype=np.float32)
+    return sd
+
+
+def synthetic_basic_sd(sizes, units: int, seed: int, bn: bool = True) -> 'OrderedDict[str, np.ndarray]':
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    idx, ci = 0, 1
+    for k in sizes:
+        sd[f'features.features.{idx}.weight'] = (rs.randn(units, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        if not bn:
+            sd[f'features.features.{idx}.bias'] = (rs.randn(units) * 0.1).astype(np.float32)
+        idx += 1
+        if bn:
+            p = f'features.features.{idx}'
+            sd[p + '.weight'] = (1.0 + 0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.bias'] = (0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.running_mean'] = (0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.running_var'] = (1.0 + 0.2 * rs.rand(units)).astype(np.float32)
+            sd[p + '.num_batches_tracked'] = np.asarray(0, dtype=np.int64)
+            idx += 1
+        sd[f'features.features.{idx}.weight'] = np.asarray([0.25 + 0.05 * rs.rand()], dtype=np.float32)
+        idx += 1
+        ci = units
+    sd['classifier.weight'] = (rs.randn(1, units, 1, 1) * np.sqrt(1.0 / units)).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([-1.0], dtype=np.float32)
+    return sd

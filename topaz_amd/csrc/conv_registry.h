@@ -1,0 +1,51 @@
+// Registry of compiled conv_mfma_kernel instantiations.  Each conv_inst_*.hip translation
+// unit registers its kernels at load time; the runtime picks one by (dims, K, dil, MT, CIN1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_mfma.h"
+
+namespace tpz {
+
+struct ConvKernelInfo {
+    int dims, K, D, MT, cin1;
+    int TD, TH, TW, KG, KP, NCH, NSTEP, W_FLOATS, lds_bytes;
+    hipError_t (*launch)(const ConvArgs&, dim3 grid, hipStream_t);
+};
+
+void register_conv(const ConvKernelInfo& info);
+const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1);
+
+template <class C>
+hipError_t launch_conv_cfg(const ConvArgs& a, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(256), C::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+template <class C>
+struct ConvRegistrar {
+    ConvRegistrar() {
+        ConvKernelInfo i;
+        i.dims = C::DIMS; i.K = C::K; i.D = C::D; i.MT = C::MT; i.cin1 = C::CIN1 ? 1 : 0;
+        i.TD = C::TD; i.TH = C::TH; i.TW = C::TW; i.KG = C::KG; i.KP = C::KP; i.NCH = C::NCH;
+        i.NSTEP = C::NSTEP; i.W_FLOATS = C::W_FLOATS; i.lds_bytes = C::LDS_BYTES;
+        i.launch = &launch_conv_cfg<C>;
+        register_conv(i);
+    }
+};
+
+#define TPZ_CAT2(a, b) a##b
+#define TPZ_CAT(a, b) TPZ_CAT2(a, b)
+// 2-D kernels: DIMS=2, TD=1
+#define TPZ_CONV2D(K, D, MT, TH, TW, KG, CIN1) \
+    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, 1, TH, TW, KG, CIN1, 2>> TPZ_CAT(tpz_reg_, __COUNTER__);
+#define TPZ_CONV3D(K, D, MT, TD, TH, TW, KG, CIN1) \
+    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, TD, TH, TW, KG, CIN1, 3>> TPZ_CAT(tpz_reg_, __COUNTER__);
+
+}  // namespace tpz

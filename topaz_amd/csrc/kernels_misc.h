@@ -1,0 +1,32 @@
+// launch helpers implemented in kernels_misc.hip and nms.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_mfma.h"
+
+namespace tpz {
+
+hipError_t launch_conv_direct(const ConvArgs& a, const float* d_w, int K, int KZ, int dil, hipStream_t s);
+hipError_t launch_maxpool2(const float* in, float* out, int C, int D, int H, int W, int dims, hipStream_t s);
+hipError_t launch_meanstd(const float* x, int D, int H, int W, long long ps, int pitch, int unbiased, int mode,
+                          const float* d_g, double* d_part, int part_blocks, float* d_out, hipStream_t s);
+hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float shift, hipStream_t s);
+hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* dst, long long dps, int dpitch, int bd,
+                           int bh, int bw, hipStream_t s);
+hipError_t launch_extract_tile3d(const float* tomo, int D, int H, int W, int i0, int j0, int k0, int d,
+                                 const float* d_g, float* tile, hipStream_t s);
+
+hipError_t nms_mark(const float* score, size_t n, float thr, uint8_t* status, uint32_t* cand, unsigned int* counters,
+                    hipStream_t s);
+hipError_t nms2d_iter(const float* score, int H, int W, int r, const int* halfw, uint8_t* status,
+                      const uint32_t* cand, unsigned int ncand, unsigned int* counters, hipStream_t s);
+hipError_t nms3d_iter(const float* score, long long n, const int* deltas, int ndelta, uint8_t* status,
+                      const uint32_t* cand, unsigned int ncand, unsigned int* counters, hipStream_t s);
+hipError_t nms_gather(const float* score, const uint8_t* status, const uint32_t* cand, unsigned int ncand,
+                      uint64_t* keys, unsigned int* counters, hipStream_t s);
+hipError_t fill_u64(uint64_t* p, size_t lo, size_t hi, uint64_t v, hipStream_t s);
+hipError_t bitonic_sort_desc(uint64_t* keys, size_t npow2, hipStream_t s);
+hipError_t nms_write(const uint64_t* keys, unsigned int n, const float* score, int H, int W, int dims,
+                     int32_t* coords, float* out_scores, hipStream_t s);
+
+}  // namespace tpz

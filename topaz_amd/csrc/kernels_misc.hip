@@ -1,0 +1,249 @@
+// HBM-bound helper kernels of the hot path: direct convolution for 1-output-channel layers
+// and 1->1 filters, 2x max-pool, mean/std reductions, affine maps, crop/paste and 3-D tiling.
+#include <hip/hip_runtime.h>
+#include "conv_mfma.h"
+#include "kernels_misc.h"
+
+namespace tpz {
+
+// ------------------------------------------------------------------------------------------
+// Direct convolution, one thread per output pixel per output channel.  Used where M (= Cout)
+// is 1 and the matrix cores have nothing to do: the U-Net output convs (denoising/models.py:127,
+// 512), the 1->1 Gaussian / inverse-Gaussian / affine filters (filters.py:28-96).
+// Weights are read through the scalar cache (uniform addresses), inputs through L1/L2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, const float* __restrict__ w, int K,
+                                                          int KZ, int dil) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int oz = blockIdx.z % a.Dout;
+    const int co = blockIdx.z / a.Dout;
+    if (ox >= a.Wout || oy >= a.Hout) return;
+    float in_scale = 1.f, in_shift = 0.f, out_scale = 1.f, out_shift = 0.f;
+    if (a.nrm) { in_scale = a.nrm[0]; in_shift = a.nrm[1]; out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
+    const bool norm1 = (a.norm_src & 1) != 0;
+    float acc = 0.f;
+    const float* wc = w + (size_t)co * a.Cin * KZ * K * K;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float* src = a.in + (long long)ci * a.cs1;
+        for (int kz = 0; kz < KZ; ++kz) {
+            const int gz = (KZ > 1) ? oz - a.pad + kz * dil : 0;
+            if ((unsigned)gz >= (unsigned)a.Din) continue;
+            for (int ky = 0; ky < K; ++ky) {
+                const int gy = oy - a.pad + ky * dil;
+                if ((unsigned)gy >= (unsigned)a.Hin) continue;
+                const float* row = src + (long long)gz * a.ps1 + (long long)gy * a.pitch1;
+                const float* wr = wc + ((size_t)(ci * KZ + kz) * K + ky) * K;
+                for (int kx = 0; kx < K; ++kx) {
+                    const int gx = ox - a.pad + kx * dil;
+                    if ((unsigned)gx < (unsigned)a.Win) {
+                        float v = row[gx];
+                        if (norm1) v = v * in_scale + in_shift;
+                        acc = fmaf(wr[kx], v, acc);
+                    }
+                }
+            }
+        }
+    }
+    float v = acc;
+    if (a.bias) v += a.bias[co];
+    v = v > 0.f ? v : v * a.slope;
+    if (a.norm_out) v = v * out_scale + out_shift;
+    a.out[((size_t)co * a.Dout + oz) * a.Hout * a.Wout + (size_t)oy * a.Wout + ox] = v;
+}
+
+hipError_t launch_conv_direct(const ConvArgs& a, const float* d_w, int K, int KZ, int dil, hipStream_t s) {
+    dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.Dout * a.Cout);
+    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, a, d_w, K, KZ, dil);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(2) / MaxPool3d(2), floor mode (denoising/models.py:81-97,459-479)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                       int D, int H, int W, int Do, int Ho, int Wo, int dims) {
+    const size_t n = (size_t)C * Do * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        size_t t = i / Wo;
+        const int y = (int)(t % Ho);
+        t /= Ho;
+        const int z = (int)(t % Do);
+        const int c = (int)(t / Do);
+        const float* p = in + (((size_t)c * D + (dims == 3 ? 2 * z : 0)) * H + 2 * y) * W + 2 * x;
+        float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+        if (dims == 3) {
+            const float* q = p + (size_t)H * W;
+            m = fmaxf(m, fmaxf(fmaxf(q[0], q[1]), fmaxf(q[W], q[W + 1])));
+        }
+        out[i] = m;
+    }
+}
+
+hipError_t launch_maxpool2(const float* in, float* out, int C, int D, int H, int W, int dims, hipStream_t s) {
+    const int Do = dims == 3 ? D / 2 : 1, Ho = H / 2, Wo = W / 2;
+    const size_t n = (size_t)C * Do * Ho * Wo;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(blocks), dim3(256), 0, s, in, out, C, D, H, W, Do, Ho, Wo, dims);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// mean / std of a (strided) 3-D box, deterministic two-stage reduction in fp64.
+// Stage 1 writes per-block partial (sum, sumsq); stage 2 (one block) folds them in fixed order
+// and emits {mean, std} or directly the normalisation parameters the conv kernels consume.
+// torch.std is unbiased (N-1), numpy.std is population (N)  (denoise.py:283 vs :343,:388).
+// sum of squares about a pilot value (the first element) keeps the one-pass variance stable.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void meanstd_partial_kernel(const float* __restrict__ x, int D, int H, int W,
+                                                              long long ps, int pitch, double* __restrict__ part) {
+    __shared__ double s1[4], s2[4];
+    const size_t n = (size_t)D * H * W;
+    const float pilot = x[0];
+    double a = 0.0, b = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const size_t t = i / W;
+        const int yy = (int)(t % H);
+        const int zz = (int)(t / H);
+        const double v = (double)x[(long long)zz * ps + (long long)yy * pitch + xx] - (double)pilot;
+        a += v;
+        b += v * v;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s1[wv] = a; s2[wv] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = s1[0] + s1[1] + s1[2] + s1[3];
+        part[2 * blockIdx.x + 1] = s2[0] + s2[1] + s2[2] + s2[3];
+    }
+}
+
+// mode 0: out = {mean, std}
+// mode 1: out = {1/std, -mean/std, std, mean}                        (Denoise._denoise, denoise.py:283-295)
+// mode 2: out = {1/std, -mean/std, std*gstd, mean*gstd + gmean}      (3-D tiles: ..., then *std+mu of the volume, :355)
+__global__ __launch_bounds__(256) void meanstd_final_kernel(const double* __restrict__ part, int nblocks,
+                                                            const float* __restrict__ x0, double n, int unbiased,
+                                                            int mode, const float* __restrict__ g, float* __restrict__ out) {
+    __shared__ double s1[4], s2[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s1[wv] = a; s2[wv] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sa = s1[0] + s1[1] + s1[2] + s1[3];
+        const double sb = s2[0] + s2[1] + s2[2] + s2[3];
+        const double dm = sa / n;
+        const double mean = dm + (double)x0[0];
+        double var = (sb - sa * dm) / (unbiased ? (n - 1.0) : n);
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)mean, sd = (float)sqrt(var);
+        if (mode == 0) {
+            out[0] = mu; out[1] = sd;
+        } else {
+            // the reference computes (x - mu)/std and pred*std + mu in fp32 (denoise.py:284,295)
+            out[0] = 1.0f / sd;
+            out[1] = -mu / sd;
+            if (mode == 1) { out[2] = sd; out[3] = mu; }
+            else { out[2] = sd * g[1]; out[3] = mu * g[1] + g[0]; }
+        }
+    }
+}
+
+hipError_t launch_meanstd(const float* x, int D, int H, int W, long long ps, int pitch, int unbiased, int mode,
+                          const float* d_g, double* d_part, int part_blocks, float* d_out, hipStream_t s) {
+    const size_t n = (size_t)D * H * W;
+    int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (blocks < 1) blocks = 1;
+    if (blocks > part_blocks) blocks = part_blocks;
+    hipLaunchKernelGGL(meanstd_partial_kernel, dim3(blocks), dim3(256), 0, s, x, D, H, W, ps, pitch, d_part);
+    hipLaunchKernelGGL(meanstd_final_kernel, dim3(1), dim3(256), 0, s, d_part, blocks, x, (double)n, unbiased, mode,
+                       d_g, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise affine y = x*scale + shift (host scalars) or with device params p[si], p[hi]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                     float scale, float shift) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = x[i] * scale + shift;
+}
+
+hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float shift, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(affine_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, scale, shift);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// copy a box: dst[dz0+z][dy0+y][dx0+x] = src[sz0+z][sy0+y][sx0+x]   (stitching, denoise.py:322,365-369)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_box_kernel(const float* __restrict__ src, long long sps, int spitch,
+                                                       float* __restrict__ dst, long long dps, int dpitch, int bd,
+                                                       int bh, int bw) {
+    const size_t n = (size_t)bd * bh * bw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % bw);
+        const size_t t = i / bw;
+        const int y = (int)(t % bh);
+        const int z = (int)(t / bh);
+        dst[(long long)z * dps + (long long)y * dpitch + x] = src[(long long)z * sps + (long long)y * spitch + x];
+    }
+}
+
+hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* dst, long long dps, int dpitch, int bd,
+                           int bh, int bw, hipStream_t s) {
+    const size_t n = (size_t)bd * bh * bw;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(copy_box_kernel, dim3(blocks), dim3(256), 0, s, src, sps, spitch, dst, dps, dpitch, bd, bh, bw);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// PatchDataset.__getitem__ (denoising/datasets.py:426-468) fused with the global normalisation
+// (denoise.py:355): tile[d][d][d] = ((inside ? tomo : 0) - mu)/std, with g = {mu, std} on device.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void extract_tile3d_kernel(const float* __restrict__ tomo, int D, int H, int W,
+                                                             int i0, int j0, int k0, int d, const float* __restrict__ g,
+                                                             float* __restrict__ tile) {
+    const size_t n = (size_t)d * d * d;
+    const float mu = g[0], sd = g[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % d);
+        const size_t t = i / d;
+        const int y = (int)(t % d);
+        const int z = (int)(t / d);
+        const int gz = i0 + z, gy = j0 + y, gx = k0 + x;
+        float v = 0.f;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+            v = tomo[((size_t)gz * H + gy) * W + gx];
+        tile[i] = (v - mu) / sd;
+    }
+}
+
+hipError_t launch_extract_tile3d(const float* tomo, int D, int H, int W, int i0, int j0, int k0, int d,
+                                 const float* d_g, float* tile, hipStream_t s) {
+    const size_t n = (size_t)d * d * d;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(extract_tile3d_kernel, dim3(blocks), dim3(256), 0, s, tomo, D, H, W, i0, j0, k0, d, d_g, tile);
+    return hipGetLastError();
+}
+
+}  // namespace tpz

@@ -1,0 +1,288 @@
+// Greedy non-maximum suppression as a parallel fix-point, bit-identical to the sequential
+// reference loop (topaz/algorithms.py:25-63 2-D, :66-103 3-D).
+//
+// Greedy: visit pixels in descending score; a pixel above the threshold is a pick iff no
+// earlier pick's suppression set contains it.  Equivalently, with "priority" = visiting order:
+//     p is SELECTED   iff every higher-priority candidate q with p in Supp(q) is SUPPRESSED
+//     p is SUPPRESSED iff some higher-priority candidate q with p in Supp(q) is SELECTED
+// which is iterated to its (unique) fix-point.  States only move UNDECIDED -> final and a final
+// state is always correct when written, so kernels may read states other threads are updating.
+//
+// Supp(q) in 2-D (algorithms.py:58-61): flat = clip(qy+ii,0,H)*W + clip(qx+jj,0,W), ii^2+jj^2<=r^2.
+//   The upper clip bound is W (not W-1): offsets past the right edge land on flat index
+//   (y'+1)*W + 0, i.e. COLUMN 0 OF THE NEXT ROW is suppressed; offsets past the bottom fall
+//   outside the array.  Low-side clipping only re-adds pixels the unclipped disk already holds.
+//   => p=(py,px) is in Supp(q) iff (py-qy)^2+(px-qx)^2 <= r^2, or
+//      px==0, py>=1 and (py-1-qy)^2 + (W-qx)^2 <= r^2.
+// Supp(q) in 3-D (algorithms.py:78-79,100-101): {q + ii*zs + jj*ys + kk}, no clipping at all
+//   (deltas wrap across rows/planes); the delta set is symmetric.
+// Priority: descending score, ties by DESCENDING flat index (stable argsort reversed);
+//   -0.0 == +0.0, NaN sorts above everything and passes `A[i] <= threshold` like in numpy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels_misc.h"
+
+namespace tpz {
+
+enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_SELECTED = 2, ST_SUPPRESSED = 3 };
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;                    // -0.0 compares equal to +0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t prio_key(float f, uint32_t idx) {
+    return ((uint64_t)orderable(f) << 32) | idx;
+}
+
+__global__ __launch_bounds__(256) void nms_mark_kernel(const float* __restrict__ score, size_t n, float thr,
+                                                       uint8_t* __restrict__ status, uint32_t* __restrict__ cand,
+                                                       unsigned int* __restrict__ counters) {
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + threadIdx.x;
+        bool is_c = false;
+        if (i < n) {
+            const float s = score[i];
+            is_c = !(s <= thr);
+            status[i] = is_c ? ST_UNDECIDED : ST_NONE;
+        }
+        const unsigned long long m = __ballot(is_c);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned int pos = 0;
+            if (lane == 0) pos = atomicAdd(&counters[0], (unsigned int)__popcll(m));
+            pos = __shfl(pos, 0, 64);
+            if (is_c) cand[pos + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        }
+    }
+}
+
+// one relaxation sweep over the candidate list (2-D)
+__global__ __launch_bounds__(256) void nms2d_iter_kernel(const float* __restrict__ score, int H, int W, int r,
+                                                         const int* __restrict__ halfw, uint8_t* status,
+                                                         const uint32_t* __restrict__ cand, unsigned int ncand,
+                                                         unsigned int* __restrict__ counters) {
+    unsigned int remaining = 0;
+    for (unsigned int c = blockIdx.x * 256 + threadIdx.x; c < ncand; c += gridDim.x * 256) {
+        const uint32_t p = cand[c];
+        if (status[p] != ST_UNDECIDED) continue;
+        const int py = (int)(p / (uint32_t)W), px = (int)(p % (uint32_t)W);
+        const uint64_t kp = prio_key(score[p], p);
+        bool suppressed = false, blocked = false;
+        for (int dy = -r; dy <= r && !suppressed; ++dy) {
+            const int qy = py + dy;
+            if ((unsigned)qy >= (unsigned)H) continue;
+            const int hw = halfw[dy + r];
+            const int x_lo = max(px - hw, 0), x_hi = min(px + hw, W - 1);
+            const size_t rowb = (size_t)qy * W;
+            for (int qx = x_lo; qx <= x_hi; ++qx) {
+                const uint8_t st = status[rowb + qx];
+                if (st == ST_NONE || st == ST_SUPPRESSED) continue;
+                const uint32_t q = (uint32_t)(rowb + qx);
+                if (prio_key(score[q], q) > kp) {
+                    if (st == ST_SELECTED) { suppressed = true; break; }
+                    blocked = true;
+                }
+            }
+        }
+        if (!suppressed && px == 0 && py >= 1) {
+            // right-edge wrap: picks near column W-1 of rows around py-1 suppress (py, 0)
+            for (int dy = -r; dy <= r && !suppressed; ++dy) {
+                const int qy = py - 1 + dy;            // q row; offset ii = -dy lands on row py-1
+                if ((unsigned)qy >= (unsigned)H) continue;
+                const int hw = halfw[dy + r];
+                // need W - qx <= hw  ->  qx >= W - hw
+                const int x_lo = max(W - hw, 0);
+                const size_t rowb = (size_t)qy * W;
+                for (int qx = x_lo; qx <= W - 1; ++qx) {
+                    const uint8_t st = status[rowb + qx];
+                    if (st == ST_NONE || st == ST_SUPPRESSED) continue;
+                    const uint32_t q = (uint32_t)(rowb + qx);
+                    if (prio_key(score[q], q) > kp) {
+                        if (st == ST_SELECTED) { suppressed = true; break; }
+                        blocked = true;
+                    }
+                }
+            }
+        }
+        if (suppressed) status[p] = ST_SUPPRESSED;
+        else if (!blocked) status[p] = ST_SELECTED;
+        else ++remaining;
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) remaining += __shfl_xor(remaining, o, 64);
+    if ((threadIdx.x & 63) == 0 && remaining) atomicAdd(&counters[1], remaining);
+}
+
+// one relaxation sweep (3-D, flat-index deltas with wrap-around)
+__global__ __launch_bounds__(256) void nms3d_iter_kernel(const float* __restrict__ score, long long n,
+                                                         const int* __restrict__ deltas, int ndelta, uint8_t* status,
+                                                         const uint32_t* __restrict__ cand, unsigned int ncand,
+                                                         unsigned int* __restrict__ counters) {
+    unsigned int remaining = 0;
+    for (unsigned int c = blockIdx.x * 256 + threadIdx.x; c < ncand; c += gridDim.x * 256) {
+        const uint32_t p = cand[c];
+        if (status[p] != ST_UNDECIDED) continue;
+        const uint64_t kp = prio_key(score[p], p);
+        bool suppressed = false, blocked = false;
+        for (int d = 0; d < ndelta; ++d) {
+            const long long q = (long long)p + deltas[d];
+            if (q < 0 || q >= n) continue;
+            const uint8_t st = status[q];
+            if (st == ST_NONE || st == ST_SUPPRESSED) continue;
+            if (prio_key(score[q], (uint32_t)q) > kp) {
+                if (st == ST_SELECTED) { suppressed = true; break; }
+                blocked = true;
+            }
+        }
+        if (suppressed) status[p] = ST_SUPPRESSED;
+        else if (!blocked) status[p] = ST_SELECTED;
+        else ++remaining;
+    }
+    for (int o = 32; o > 0; o >>= 1) remaining += __shfl_xor(remaining, o, 64);
+    if ((threadIdx.x & 63) == 0 && remaining) atomicAdd(&counters[1], remaining);
+}
+
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ score,
+                                                         const uint8_t* __restrict__ status,
+                                                         const uint32_t* __restrict__ cand, unsigned int ncand,
+                                                         uint64_t* __restrict__ keys,
+                                                         unsigned int* __restrict__ counters) {
+    for (unsigned int base = blockIdx.x * 256; base < ncand; base += gridDim.x * 256) {
+        const unsigned int c = base + threadIdx.x;
+        bool sel = false;
+        uint32_t p = 0;
+        if (c < ncand) { p = cand[c]; sel = status[p] == ST_SELECTED; }
+        const unsigned long long m = __ballot(sel);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned int pos = 0;
+            if (lane == 0) pos = atomicAdd(&counters[2], (unsigned int)__popcll(m));
+            pos = __shfl(pos, 0, 64);
+            if (sel) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = prio_key(score[p], p);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(uint64_t* p, size_t lo, size_t hi, uint64_t v) {
+    for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+
+// bitonic sort, descending, n a power of two.  Steps with partner distance j < 2048 run inside
+// LDS (4096 keys per block); larger distances are one global compare-exchange sweep each.
+__global__ __launch_bounds__(256) void bitonic_global_kernel(uint64_t* keys, size_t n, size_t j, size_t k) {
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n / 2; t += (size_t)gridDim.x * 256) {
+        const size_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+        const size_t l = i | j;
+        const bool desc = (i & k) == 0;
+        const uint64_t a = keys[i], b = keys[l];
+        if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[l] = a; }
+    }
+}
+
+#define BITONIC_TILE 4096
+__global__ __launch_bounds__(256) void bitonic_local_kernel(uint64_t* keys, size_t n, size_t k_lo, size_t k_hi,
+                                                            size_t j_start) {
+    // performs, on each 4096-key tile: for k = k_lo..k_hi (doubling): for j = (k == k_lo ? j_start : k/2) .. 1
+    __shared__ uint64_t s[BITONIC_TILE];
+    const size_t base = (size_t)blockIdx.x * BITONIC_TILE;
+    for (int t = threadIdx.x; t < BITONIC_TILE; t += 256) s[t] = keys[base + t];
+    __syncthreads();
+    for (size_t k = k_lo; k <= k_hi; k <<= 1) {
+        for (size_t j = (k == k_lo ? j_start : k >> 1); j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < BITONIC_TILE / 2; t += 256) {
+                const size_t i = (((size_t)t & ~(j - 1)) << 1) | ((size_t)t & (j - 1));
+                const size_t l = i | j;
+                const bool desc = ((base + i) & k) == 0;
+                const uint64_t a = s[i], b = s[l];
+                if (desc ? (a < b) : (a > b)) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < BITONIC_TILE; t += 256) keys[base + t] = s[t];
+}
+
+hipError_t bitonic_sort_desc(uint64_t* keys, size_t npow2, hipStream_t s) {
+    if (npow2 < 2) return hipSuccess;
+    if (npow2 < BITONIC_TILE) return hipErrorInvalidValue;   // caller pads to >= one tile
+    const int tiles = (int)(npow2 / BITONIC_TILE);
+    // all stages with k <= tile size: fully local
+    hipLaunchKernelGGL(bitonic_local_kernel, dim3(tiles), dim3(256), 0, s, keys, npow2, (size_t)2,
+                       (size_t)BITONIC_TILE, (size_t)1);
+    for (size_t k = (size_t)BITONIC_TILE * 2; k <= npow2; k <<= 1) {
+        size_t j = k >> 1;
+        for (; j >= BITONIC_TILE; j >>= 1) {
+            const size_t half = npow2 / 2;
+            int blocks = (int)((half + 255) / 256 < 8192 ? (half + 255) / 256 : 8192);
+            hipLaunchKernelGGL(bitonic_global_kernel, dim3(blocks), dim3(256), 0, s, keys, npow2, j, k);
+        }
+        // remaining j = TILE/2 .. 1 of this k inside LDS
+        hipLaunchKernelGGL(bitonic_local_kernel, dim3(tiles), dim3(256), 0, s, keys, npow2, k, k, j);
+    }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void nms_write_kernel(const uint64_t* __restrict__ keys, unsigned int n,
+                                                        const float* __restrict__ score, int H, int W, int dims,
+                                                        int32_t* __restrict__ coords, float* __restrict__ out_scores) {
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t p = (uint32_t)(keys[i] & 0xffffffffull);
+        out_scores[i] = score[p];
+        const uint32_t x = p % (uint32_t)W;
+        const uint32_t t = p / (uint32_t)W;
+        if (dims == 2) {
+            coords[2 * i] = (int32_t)x;
+            coords[2 * i + 1] = (int32_t)t;
+        } else {
+            coords[3 * i] = (int32_t)x;
+            coords[3 * i + 1] = (int32_t)(t % (uint32_t)H);
+            coords[3 * i + 2] = (int32_t)(t / (uint32_t)H);
+        }
+    }
+}
+
+// ---- host-side launch helpers (called from runtime.hip) -----------------------------------------
+static inline int nblocks(size_t n, int cap = 8192) {
+    size_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < (size_t)cap ? b : (size_t)cap);
+}
+
+hipError_t nms_mark(const float* score, size_t n, float thr, uint8_t* status, uint32_t* cand, unsigned int* counters,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(nms_mark_kernel, dim3(nblocks(n)), dim3(256), 0, s, score, n, thr, status, cand, counters);
+    return hipGetLastError();
+}
+hipError_t nms2d_iter(const float* score, int H, int W, int r, const int* halfw, uint8_t* status,
+                      const uint32_t* cand, unsigned int ncand, unsigned int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(nms2d_iter_kernel, dim3(nblocks(ncand, 65535)), dim3(256), 0, s, score, H, W, r, halfw, status,
+                       cand, ncand, counters);
+    return hipGetLastError();
+}
+hipError_t nms3d_iter(const float* score, long long n, const int* deltas, int ndelta, uint8_t* status,
+                      const uint32_t* cand, unsigned int ncand, unsigned int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(nms3d_iter_kernel, dim3(nblocks(ncand, 65535)), dim3(256), 0, s, score, n, deltas, ndelta,
+                       status, cand, ncand, counters);
+    return hipGetLastError();
+}
+hipError_t nms_gather(const float* score, const uint8_t* status, const uint32_t* cand, unsigned int ncand,
+                      uint64_t* keys, unsigned int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(nblocks(ncand)), dim3(256), 0, s, score, status, cand, ncand, keys,
+                       counters);
+    return hipGetLastError();
+}
+hipError_t fill_u64(uint64_t* p, size_t lo, size_t hi, uint64_t v, hipStream_t s) {
+    if (hi <= lo) return hipSuccess;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(nblocks(hi - lo)), dim3(256), 0, s, p, lo, hi, v);
+    return hipGetLastError();
+}
+hipError_t nms_write(const uint64_t* keys, unsigned int n, const float* score, int H, int W, int dims,
+                     int32_t* coords, float* out_scores, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(nms_write_kernel, dim3(nblocks(n)), dim3(256), 0, s, keys, n, score, H, W, dims, coords,
+                       out_scores);
+    return hipGetLastError();
+}
+
+}  // namespace tpz

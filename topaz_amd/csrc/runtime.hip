@@ -1,0 +1,890 @@
+// libtopaz_hip.so runtime: context, weight packing, layer-program executor, denoise / NMS drivers
+// and the C-ABI declared in include/topaz_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/topaz_hip.h"
+#include "conv_registry.h"
+#include "kernels_misc.h"
+
+using namespace tpz;
+
+// ------------------------------------------------------------------------------------------------
+// kernel registry
+// ------------------------------------------------------------------------------------------------
+namespace tpz {
+static std::vector<ConvKernelInfo>& registry() {
+    static std::vector<ConvKernelInfo> r;
+    return r;
+}
+void register_conv(const ConvKernelInfo& info) { registry().push_back(info); }
+const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1) {
+    for (const auto& k : registry())
+        if (k.dims == dims && k.K == K && k.D == D && k.MT == MT && k.cin1 == (cin1 ? 1 : 0)) return &k;
+    return nullptr;
+}
+}  // namespace tpz
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static std::string g_last_error;
+
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops;
+};
+
+struct tpz_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    struct Buf {
+        void* p;
+        size_t bytes;
+        bool used;
+    };
+    std::vector<Buf> pool;
+    double* d_part = nullptr;     // reduction partials
+    float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
+    int nrm_next = 0;
+    unsigned int* d_counters = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> free_events;
+    double acc_ms[4] = {0, 0, 0, 0};
+    long long acc_n[4] = {0, 0, 0, 0};
+    double acc_flops[4] = {0, 0, 0, 0};
+};
+
+static const int PART_BLOCKS = 1024;
+static const int NRM_RING = 4096;
+
+static int fail(tpz_ctx* ctx, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return 1;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+static void* pool_alloc(tpz_ctx* ctx, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
+        auto& b = ctx->pool[i];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].used = true;
+        return ctx->pool[best].p;
+    }
+    void* p = nullptr;
+    // round up so slightly larger requests can reuse the buffer
+    size_t rounded = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    if (hipMalloc(&p, rounded) != hipSuccess) {
+        // drop unused cached buffers and retry once
+        for (auto it = ctx->pool.begin(); it != ctx->pool.end();) {
+            if (!it->used) { (void)hipFree(it->p); it = ctx->pool.erase(it); }
+            else ++it;
+        }
+        if (hipMalloc(&p, rounded) != hipSuccess) return nullptr;
+    }
+    ctx->pool.push_back({p, rounded, true});
+    return p;
+}
+static void pool_release(tpz_ctx* ctx, void* p) {
+    for (auto& b : ctx->pool)
+        if (b.p == p) { b.used = false; return; }
+}
+
+static float* next_nrm(tpz_ctx* ctx) {
+    if (ctx->nrm_next >= NRM_RING) {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->nrm_next = 0;
+    }
+    return ctx->d_nrm + 4 * (ctx->nrm_next++);
+}
+
+// ---- profiling helpers
+static void prof_begin(tpz_ctx* ctx, int cls, double flops) {
+    if (!ctx->prof) return;
+    ProfRec r;
+    r.cls = cls;
+    r.flops = flops;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    r.e0 = get();
+    r.e1 = get();
+    (void)hipEventRecord(r.e0, ctx->stream);
+    ctx->recs.push_back(r);
+}
+static void prof_end(tpz_ctx* ctx) {
+    if (!ctx->prof || ctx->recs.empty()) return;
+    (void)hipEventRecord(ctx->recs.back().e1, ctx->stream);
+}
+static void prof_flush(tpz_ctx* ctx) {
+    if (ctx->recs.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        ctx->acc_ms[r.cls] += ms;
+        ctx->acc_n[r.cls] += 1;
+        ctx->acc_flops[r.cls] += r.flops;
+        ctx->free_events.push_back(r.e0);
+        ctx->free_events.push_back(r.e1);
+    }
+    ctx->recs.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct LayerRT {
+    tpz_layer L;
+    const ConvKernelInfo* ki = nullptr;   // nullptr -> direct kernel
+    int n_cog = 1, n_chunks = 1, cog_inner = 1;
+    float* d_wpk = nullptr;               // packed (MFMA) or raw (direct) weights
+    float* d_bias = nullptr;
+    float* d_post_scale = nullptr;
+    float* d_post_shift = nullptr;
+    float* d_head_w = nullptr;
+    float head_b = 0.f;
+};
+
+struct tpz_model {
+    tpz_ctx* ctx = nullptr;
+    std::vector<LayerRT> layers;
+    int n_slots = 0;
+    std::vector<int> last_use;
+    std::vector<void*> dev_allocs;
+};
+
+struct Slot {
+    float* p = nullptr;
+    int C = 0, D = 1, H = 0, W = 0;
+    long long cs = 0, ps = 0;
+    int pitch = 0;
+    bool owned = false;
+    bool set = false;
+};
+
+static void set_dense(Slot& s, float* p, int C, int D, int H, int W) {
+    s.p = p; s.C = C; s.D = D; s.H = H; s.W = W;
+    s.pitch = W; s.ps = (long long)H * W; s.cs = s.ps * D;
+    s.set = true;
+}
+
+static int upload(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** out) {
+    float* d = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&d, std::max<size_t>(n, 4) * sizeof(float)));
+    HIPCHK(ctx, hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice));
+    if (m) m->dev_allocs.push_back(d);
+    *out = d;
+    return 0;
+}
+
+static const int MT_CHOICES[] = {16, 32, 48, 64, 96, 128};
+
+// choose the MFMA instantiation for a conv layer; returns nullptr when the direct kernel must be used
+static const ConvKernelInfo* choose_kernel(const tpz_layer& L, bool* cin1_out) {
+    if (L.cout == 1 && !L.head) return nullptr;      // M = 1: nothing for the matrix cores to do
+    const bool cin1 = (L.cin == 1 && L.src2 < 0);
+    const ConvKernelInfo* best = nullptr;
+    int best_padded = 1 << 30;
+    for (int mt : MT_CHOICES) {
+        const ConvKernelInfo* k = find_conv(L.dims, L.k, L.dil, mt, cin1);
+        if (!k) continue;
+        const int padded = (L.cout + mt - 1) / mt * mt;
+        if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
+            best = k;
+            best_padded = padded;
+        }
+    }
+    *cin1_out = cin1;
+    return best;
+}
+
+// weights [cout][cin][kz][ky][kx] -> per (co-group, channel chunk) blocks in A-fragment lane order:
+//   block[step][mf][k(0..3)][i(0..15)]  with lane = k*16 + i   (conv_mfma.h)
+static void pack_weights(const ConvKernelInfo& ki, const float* w, int cout, int cin, int n_cog, int n_chunks,
+                         std::vector<float>& out) {
+    const int K = ki.K, KZ = ki.dims == 3 ? K : 1, MW = ki.MT / 16;
+    out.assign((size_t)n_cog * n_chunks * ki.W_FLOATS, 0.f);
+    const size_t taps = (size_t)KZ * K * K;
+    for (int cog = 0; cog < n_cog; ++cog)
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            float* blk = out.data() + ((size_t)cog * n_chunks + ch) * ki.W_FLOATS;
+            for (int step = 0; step < ki.NSTEP; ++step) {
+                for (int mf = 0; mf < MW; ++mf)
+                    for (int k = 0; k < 4; ++k)
+                        for (int i = 0; i < 16; ++i) {
+                            const int co = cog * ki.MT + mf * 16 + i;
+                            int ci, kz, ky, kx;
+                            if (ki.cin1) {
+                                const int ng = ki.KP / 4;
+                                const int kg = step % ng;
+                                const int t = step / ng;
+                                ky = t % K;
+                                kz = t / K;
+                                kx = kg * 4 + k;
+                                ci = 0;
+                            } else {
+                                int t = step;
+                                kx = t % K; t /= K;
+                                ky = t % K; t /= K;
+                                kz = t % KZ; t /= KZ;
+                                const int kg = t;
+                                ci = ch * ki.NCH + kg * 4 + k;
+                            }
+                            float v = 0.f;
+                            if (co < cout && ci < cin && kx < K)
+                                v = w[((size_t)co * cin + ci) * taps + ((size_t)kz * K + ky) * K + kx];
+                            blk[((size_t)step * MW + mf) * 64 + k * 16 + i] = v;
+                        }
+            }
+        }
+}
+
+static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const float* blob, size_t n_floats,
+                         LayerRT& rt) {
+    rt.L = L;
+    if (L.op != TPZ_OP_CONV) return 0;
+    if (L.dims != 2 && L.dims != 3) return fail(ctx, "conv: dims must be 2 or 3");
+    const size_t taps = (L.dims == 3 ? (size_t)L.k * L.k * L.k : (size_t)L.k * L.k);
+    const size_t wn = (size_t)L.cout * L.cin * taps;
+    if (L.w_off < 0 || (size_t)L.w_off + wn > n_floats) return fail(ctx, "conv: weight offset out of range");
+    const float* w = blob + L.w_off;
+    bool cin1 = false;
+    rt.ki = choose_kernel(L, &cin1);
+    if (rt.ki) {
+        const ConvKernelInfo& ki = *rt.ki;
+        rt.n_cog = (L.cout + ki.MT - 1) / ki.MT;
+        rt.n_chunks = ki.cin1 ? 1 : (L.cin + ki.NCH - 1) / ki.NCH;
+        rt.cog_inner = L.head ? rt.n_cog : 1;
+        std::vector<float> packed;
+        pack_weights(ki, w, L.cout, L.cin, rt.n_cog, rt.n_chunks, packed);
+        if (upload(ctx, m, packed.data(), packed.size(), &rt.d_wpk)) return 1;
+    } else {
+        if (L.src2 >= 0 || L.res >= 0 || L.head || L.post_scale_off >= 0)
+            return fail(ctx, "conv k=%d dil=%d cin=%d cout=%d dims=%d: no MFMA kernel compiled and the direct "
+                        "kernel has no concat/residual/head epilogue", L.k, L.dil, L.cin, L.cout, L.dims);
+        if (upload(ctx, m, w, wn, &rt.d_wpk)) return 1;
+    }
+    if (L.b_off >= 0) {
+        if ((size_t)L.b_off + L.cout > n_floats) return fail(ctx, "conv: bias offset out of range");
+        if (upload(ctx, m, blob + L.b_off, L.cout, &rt.d_bias)) return 1;
+    }
+    if (L.post_scale_off >= 0) {
+        if (upload(ctx, m, blob + L.post_scale_off, L.cout, &rt.d_post_scale)) return 1;
+        if (upload(ctx, m, blob + L.post_shift_off, L.cout, &rt.d_post_shift)) return 1;
+    }
+    if (L.head) {
+        if (upload(ctx, m, blob + L.head_w_off, L.cout, &rt.d_head_w)) return 1;
+        rt.head_b = blob[L.head_b_off];
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// executor
+// ------------------------------------------------------------------------------------------------
+static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* s2, const Slot* sres, Slot& dst,
+                    const float* d_nrm, int norm_src, int norm_out) {
+    const tpz_layer& L = rt.L;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = s1.p;
+    a.in2 = s2 ? s2->p : nullptr;
+    a.wpk = rt.d_wpk;
+    a.bias = rt.d_bias;
+    a.res = sres ? sres->p : nullptr;
+    a.post_scale = rt.d_post_scale;
+    a.post_shift = rt.d_post_shift;
+    a.head_w = rt.d_head_w;
+    a.head_b = rt.head_b;
+    a.nrm = d_nrm;
+    a.norm_src = d_nrm ? norm_src : 0;
+    a.norm_out = d_nrm ? norm_out : 0;
+    a.Cin = L.cin;
+    a.Cin1 = s1.C;
+    const Slot& geo = s2 ? *s2 : s1;
+    a.Din = geo.D; a.Hin = geo.H; a.Win = geo.W;
+    a.D1 = s1.D; a.H1 = s1.H; a.W1 = s1.W;
+    a.cs1 = s1.cs; a.ps1 = s1.ps; a.pitch1 = s1.pitch;
+    if (s2) { a.cs2 = s2->cs; a.ps2 = s2->ps; a.pitch2 = s2->pitch; }
+    a.Cout = L.cout;
+    a.Dout = dst.D; a.Hout = dst.H; a.Wout = dst.W;
+    a.pad = L.pad;
+    if (sres) { a.Dres = sres->D; a.Hres = sres->H; a.Wres = sres->W; a.res_crop = L.res_crop; }
+    a.slope = L.slope;
+    if (L.head) { a.head_out = dst.p; a.out = nullptr; }
+    else a.out = dst.p;
+    const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    if (rt.ki) {
+        const ConvKernelInfo& ki = *rt.ki;
+        a.n_chunks = rt.n_chunks;
+        a.cog_inner = rt.cog_inner;
+        a.tiles_x = (dst.W + ki.TW - 1) / ki.TW;
+        a.tiles_y = (dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
+        a.tiles_z = L.dims == 3 ? (dst.D + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
+        if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
+        dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, rt.n_cog / rt.cog_inner);
+        prof_begin(ctx, 0, flops);
+        hipError_t e = ki.launch(a, grid, ctx->stream);
+        prof_end(ctx);
+        HIPCHK(ctx, e);
+    } else {
+        if (s1.D != geo.D || s1.H != geo.H || s1.W != geo.W) return fail(ctx, "direct conv cannot upsample");
+        prof_begin(ctx, 1, flops);
+        hipError_t e = launch_conv_direct(a, rt.d_wpk, L.k, L.dims == 3 ? L.k : 1, L.dil, ctx->stream);
+        prof_end(ctx);
+        HIPCHK(ctx, e);
+    }
+    return 0;
+}
+
+// runs the layer program.  `slots` holds preset external slots (at least slot 0); the dst of the last
+// layer is written to d_out (dense).  d_nrm != nullptr: slot 0 is normalised on load wherever it is read
+// and the output is un-normalised (Denoise._denoise, topaz/denoise.py:283-295).
+static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, const float* d_nrm) {
+    tpz_ctx* ctx = m->ctx;
+    const int nl = (int)m->layers.size();
+    slots.resize(std::max<size_t>(slots.size(), (size_t)m->n_slots));
+    int rc = 0;
+    for (int i = 0; i < nl && rc == 0; ++i) {
+        const LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        const Slot& s1 = slots[L.src];
+        if (!s1.set) { rc = fail(ctx, "layer %d reads unset slot %d", i, L.src); break; }
+        Slot& dst = slots[L.dst];
+        if (L.op == TPZ_OP_CONV) {
+            const Slot* s2 = L.src2 >= 0 ? &slots[L.src2] : nullptr;
+            const Slot* sres = L.res >= 0 ? &slots[L.res] : nullptr;
+            if ((s2 && !s2->set) || (sres && !sres->set)) { rc = fail(ctx, "layer %d reads an unset slot", i); break; }
+            const Slot& geo = s2 ? *s2 : s1;
+            if (s1.C + (s2 ? s2->C : 0) != L.cin) {
+                rc = fail(ctx, "layer %d: cin %d != channels of its sources (%d)", i, L.cin, s1.C + (s2 ? s2->C : 0));
+                break;
+            }
+            const int span = L.dil * (L.k - 1);
+            const int Do = L.dims == 3 ? geo.D + 2 * L.pad - span : 1;
+            const int Ho = geo.H + 2 * L.pad - span, Wo = geo.W + 2 * L.pad - span;
+            if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input %dx%dx%d too small", i, geo.D, geo.H, geo.W); break; }
+            const int Co = L.head ? 1 : L.cout;
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, (size_t)Co * Do * Ho * Wo * sizeof(float));
+            if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
+            set_dense(dst, p, Co, Do, Ho, Wo);
+            dst.owned = (i != nl - 1);
+            if (sres && (sres->H - 2 * L.res_crop != Ho || sres->W - 2 * L.res_crop != Wo || sres->C != L.cout)) {
+                rc = fail(ctx, "layer %d: residual geometry mismatch", i);
+                break;
+            }
+            int norm_src = 0;
+            if (d_nrm) norm_src = (L.src == 0 ? 1 : 0) | (L.src2 == 0 ? 2 : 0);
+            rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, norm_src, (d_nrm && i == nl - 1) ? 1 : 0);
+        } else if (L.op == TPZ_OP_MAXPOOL2) {
+            if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
+            const int Do = L.dims == 3 ? s1.D / 2 : 1, Ho = s1.H / 2, Wo = s1.W / 2;
+            if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input too small to pool", i); break; }
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, (size_t)s1.C * Do * Ho * Wo * sizeof(float));
+            if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
+            set_dense(dst, p, s1.C, Do, Ho, Wo);
+            dst.owned = (i != nl - 1);
+            prof_begin(ctx, 2, 0);
+            hipError_t e = launch_maxpool2(s1.p, dst.p, s1.C, s1.D, s1.H, s1.W, L.dims, ctx->stream);
+            prof_end(ctx);
+            if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
+        } else {
+            rc = fail(ctx, "layer %d: unknown op %d", i, L.op);
+        }
+        // release intermediates whose last reader was this layer
+        for (int s = 0; s < m->n_slots; ++s)
+            if (slots[s].set && slots[s].owned && m->last_use[s] == i) {
+                pool_release(ctx, slots[s].p);
+                slots[s].owned = false;
+            }
+    }
+    for (auto& s : slots)
+        if (s.owned) { pool_release(ctx, s.p); s.owned = false; }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* tpz_version(void) { return "topaz_hip 0.1 (gfx950)"; }
+
+const char* tpz_last_error(tpz_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int tpz_ctx_create(int device_id, tpz_ctx** out) {
+    if (!out) return fail(nullptr, "tpz_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, "tpz_ctx_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, "tpz_ctx_create: device %d of %d", device_id, ndev);
+    tpz_ctx* ctx = new tpz_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return fail(nullptr, "hipSetDevice(%d) failed", device_id); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            delete ctx;
+            return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+                        prop.gcnArchName);
+        }
+    }
+    if (hipStreamCreate(&ctx->own_stream) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreate failed"); }
+    ctx->stream = ctx->own_stream;
+    if (hipMalloc((void**)&ctx->d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned int)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, "tpz_ctx_create: hipMalloc failed");
+    }
+    *out = ctx;
+    return 0;
+}
+
+void tpz_ctx_destroy(tpz_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
+    (void)hipFree(ctx->d_part);
+    (void)hipFree(ctx->d_nrm);
+    (void)hipFree(ctx->d_counters);
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int tpz_ctx_set_stream(tpz_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+int tpz_ctx_sync(tpz_ctx* ctx) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int tpz_model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
+                   tpz_model** out) {
+    if (!ctx || !layers || !out || n_layers < 1) return fail(ctx, "tpz_model_load: bad arguments");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    tpz_model* m = new tpz_model();
+    m->ctx = ctx;
+    int max_slot = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const tpz_layer& L = layers[i];
+        max_slot = std::max(max_slot, std::max(std::max(L.src, L.src2), std::max(L.dst, L.res)));
+        if (L.src < 0 || L.dst <= 0) { tpz_model_free(m); return fail(ctx, "layer %d: bad slot ids", i); }
+    }
+    m->n_slots = max_slot + 1;
+    m->last_use.assign(m->n_slots, -1);
+    m->layers.resize(n_layers);
+    for (int i = 0; i < n_layers; ++i) {
+        const tpz_layer& L = layers[i];
+        m->last_use[L.src] = i;
+        if (L.src2 >= 0) m->last_use[L.src2] = i;
+        if (L.res >= 0) m->last_use[L.res] = i;
+        if (prepare_layer(ctx, m, L, h_blob, n_floats, m->layers[i])) { tpz_model_free(m); return 1; }
+    }
+    *out = m;
+    return 0;
+}
+
+void tpz_model_free(tpz_model* m) {
+    if (!m) return;
+    if (m->ctx) (void)hipStreamSynchronize(m->ctx->stream);
+    for (void* p : m->dev_allocs) (void)hipFree(p);
+    delete m;
+}
+
+int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int* Wo) {
+    if (!m) return fail(nullptr, "model is NULL");
+    struct S { int C, D, H, W; };
+    std::vector<S> s(m->n_slots, S{0, 0, 0, 0});
+    s[0] = {1, D, H, W};
+    for (auto& rt : m->layers) {
+        const tpz_layer& L = rt.L;
+        const S& g = L.src2 >= 0 ? s[L.src2] : s[L.src];
+        if (L.op == TPZ_OP_CONV) {
+            const int span = L.dil * (L.k - 1);
+            s[L.dst] = {L.head ? 1 : L.cout, L.dims == 3 ? g.D + 2 * L.pad - span : 1, g.H + 2 * L.pad - span,
+                        g.W + 2 * L.pad - span};
+        } else {
+            s[L.dst] = {g.C, L.dims == 3 ? g.D / 2 : 1, g.H / 2, g.W / 2};
+        }
+    }
+    const S& o = s[m->layers.back().L.dst];
+    if (Do) *Do = o.D;
+    if (Ho) *Ho = o.H;
+    if (Wo) *Wo = o.W;
+    return 0;
+}
+
+int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out) {
+    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_model_forward: NULL argument");
+    tpz_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int Do, Ho, Wo;
+    tpz_model_out_shape(m, D, H, W, &Do, &Ho, &Wo);
+    if (Do < 1 || Ho < 1 || Wo < 1) return fail(ctx, "input %dx%dx%d too small for this model", D, H, W);
+    for (int b = 0; b < n; ++b) {
+        std::vector<Slot> slots(m->n_slots);
+        set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
+        if (run_program(m, slots, d_out + (size_t)b * Do * Ho * Wo, nullptr)) return 1;
+    }
+    return 0;
+}
+
+// ---- denoising ---------------------------------------------------------------------------------
+static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int dims) {
+    tpz_ctx* ctx = m->ctx;
+    float* nrm = next_nrm(ctx);
+    prof_begin(ctx, 2, 0);
+    hipError_t e = launch_meanstd(view.p, view.D, view.H, view.W, view.ps, view.pitch, /*unbiased*/ 1, /*mode*/ 1,
+                                  nullptr, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    std::vector<Slot> slots(m->n_slots);
+    slots[0] = view;
+    (void)dims;
+    return run_program(m, slots, d_out_dense, nrm);
+}
+
+int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out) {
+    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_2d: NULL argument");
+    tpz_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int Do, Ho, Wo;
+    tpz_model_out_shape(m, 1, 8 * 64, 8 * 64, &Do, &Ho, &Wo);
+    if (Ho != 8 * 64 || Wo != 8 * 64) return fail(ctx, "tpz_denoise_2d: the model does not preserve the image size");
+    const int s = patch + pad;
+    const bool use_patch = patch > 0 && (s < H || s < W);     // denoise.py:329-330
+    if (!use_patch) {
+        Slot v;
+        set_dense(v, const_cast<float*>(d_in), 1, 1, H, W);
+        return denoise_region(m, v, d_out, 2);
+    }
+    for (int i = 0; i < H; i += patch)
+        for (int j = 0; j < W; j += patch) {
+            const int si = std::max(0, i - pad), ei = std::min(H, i + patch + pad);
+            const int sj = std::max(0, j - pad), ej = std::min(W, j + patch + pad);
+            const int ph = ei - si, pw = ej - sj;
+            Slot v;
+            set_dense(v, const_cast<float*>(d_in) + (size_t)si * W + sj, 1, 1, ph, pw);
+            v.pitch = W;
+            v.ps = (long long)H * W;
+            v.cs = v.ps;
+            float* tmp = (float*)pool_alloc(ctx, (size_t)ph * pw * sizeof(float));
+            if (!tmp) return fail(ctx, "out of device memory");
+            int rc = denoise_region(m, v, tmp, 2);
+            if (rc == 0) {
+                const int oi = i - si, oj = j - sj;
+                const int ch = std::min(patch, std::min(H - i, ph - oi)), cw = std::min(patch, std::min(W - j, pw - oj));
+                prof_begin(ctx, 2, 0);
+                hipError_t e = launch_copy_box(tmp + (size_t)oi * pw + oj, 0, pw, d_out + (size_t)i * W + j, 0, W, 1, ch,
+                                               cw, ctx->stream);
+                prof_end(ctx);
+                if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
+            }
+            pool_release(ctx, tmp);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
+    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_3d: NULL argument");
+    tpz_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (patch < 1) {
+        Slot v;
+        set_dense(v, const_cast<float*>(d_in), 1, D, H, W);
+        return denoise_region(m, v, d_out, 3);
+    }
+    // global mean / population std (numpy, denoise.py:343)
+    float* g = next_nrm(ctx);
+    HIPCHK(ctx, launch_meanstd(d_in, D, H, W, (long long)H * W, W, 0, 0, nullptr, ctx->d_part, PART_BLOCKS, g, ctx->stream));
+    const int d = patch + 2 * pad;
+    const size_t tn = (size_t)d * d * d;
+    float* tile = (float*)pool_alloc(ctx, tn * sizeof(float));
+    float* tout = (float*)pool_alloc(ctx, tn * sizeof(float));
+    if (!tile || !tout) return fail(ctx, "out of device memory");
+    int rc = 0;
+    for (int i = 0; i < D && !rc; i += patch)
+        for (int j = 0; j < H && !rc; j += patch)
+            for (int k = 0; k < W && !rc; k += patch) {
+                prof_begin(ctx, 2, 0);
+                hipError_t e = launch_extract_tile3d(d_in, D, H, W, i - pad, j - pad, k - pad, d, g, tile, ctx->stream);
+                prof_end(ctx);
+                if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
+                float* nrm = next_nrm(ctx);
+                e = launch_meanstd(tile, d, d, d, (long long)d * d, d, 1, 2, g, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
+                if (e != hipSuccess) { rc = fail(ctx, "meanstd failed: %s", hipGetErrorString(e)); break; }
+                std::vector<Slot> slots(m->n_slots);
+                set_dense(slots[0], tile, 1, d, d, d);
+                rc = run_program(m, slots, tout, nrm);
+                if (rc) break;
+                const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
+                prof_begin(ctx, 2, 0);
+                e = launch_copy_box(tout + ((size_t)pad * d + pad) * d + pad, (long long)d * d, d,
+                                    d_out + ((size_t)i * H + j) * W + k, (long long)H * W, W, pz, py, px, ctx->stream);
+                prof_end(ctx);
+                if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
+            }
+    pool_release(ctx, tile);
+    pool_release(ctx, tout);
+    return rc;
+}
+
+int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std) {
+    if (!ctx || !d_x || !h_mean_std || n == 0) return fail(ctx, "tpz_mean_std: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float* out = next_nrm(ctx);
+    // present the vector as rows of <= 2^20 elements so int geometry cannot overflow
+    const int Wv = (int)std::min<size_t>(n, (size_t)1 << 20);
+    const size_t rows = n / Wv;
+    if (rows * (size_t)Wv != n) {
+        // fall back to a single row when n is not a multiple (n < 2^31 required)
+        if (n >= ((size_t)1 << 31)) return fail(ctx, "tpz_mean_std: n too large for a ragged vector");
+        HIPCHK(ctx, launch_meanstd(d_x, 1, 1, (int)n, 0, (int)n, unbiased, 0, nullptr, ctx->d_part, PART_BLOCKS, out, ctx->stream));
+    } else {
+        HIPCHK(ctx, launch_meanstd(d_x, 1, (int)rows, Wv, 0, Wv, unbiased, 0, nullptr, ctx->d_part, PART_BLOCKS, out, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(h_mean_std, out, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int tpz_affine(tpz_ctx* ctx, const float* d_x, size_t n, float scale, float shift, float* d_y) {
+    if (!ctx || !d_x || !d_y) return fail(ctx, "tpz_affine: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    prof_begin(ctx, 2, 0);
+    hipError_t e = launch_affine(d_x, d_y, n, scale, shift, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+// ---- single ops --------------------------------------------------------------------------------
+int tpz_conv(tpz_ctx* ctx, int dims, const float* d_in, int cin1, int D1, int H1, int W1, const float* d_in2, int cin,
+             int D, int H, int W, const float* h_w, const float* h_b, int cout, int k, int dil, int pad, float slope,
+             const float* d_res, int res_crop, const float* h_post_scale, const float* h_post_shift,
+             const float* h_head_w, float head_b, float* d_out) {
+    if (!ctx || !d_in || !h_w || !d_out) return fail(ctx, "tpz_conv: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t taps = dims == 3 ? (size_t)k * k * k : (size_t)k * k;
+    std::vector<float> blob;
+    tpz_layer L;
+    memset(&L, 0, sizeof L);
+    L.op = TPZ_OP_CONV; L.dims = dims; L.src = 0; L.src2 = d_in2 ? 1 : -1; L.dst = 3;
+    L.cin = cin; L.cout = cout; L.k = k; L.dil = dil; L.pad = pad; L.slope = slope;
+    L.res = d_res ? 2 : -1; L.res_crop = res_crop;
+    L.w_off = 0;
+    blob.insert(blob.end(), h_w, h_w + (size_t)cout * cin * taps);
+    L.b_off = -1;
+    if (h_b) { L.b_off = (int64_t)blob.size(); blob.insert(blob.end(), h_b, h_b + cout); }
+    L.post_scale_off = L.post_shift_off = -1;
+    if (h_post_scale && h_post_shift) {
+        L.post_scale_off = (int64_t)blob.size(); blob.insert(blob.end(), h_post_scale, h_post_scale + cout);
+        L.post_shift_off = (int64_t)blob.size(); blob.insert(blob.end(), h_post_shift, h_post_shift + cout);
+    }
+    L.head = h_head_w ? 1 : 0;
+    if (h_head_w) {
+        L.head_w_off = (int64_t)blob.size(); blob.insert(blob.end(), h_head_w, h_head_w + cout);
+        L.head_b_off = (int64_t)blob.size(); blob.push_back(head_b);
+    }
+    tpz_model* m = nullptr;
+    if (tpz_model_load(ctx, &L, 1, blob.data(), blob.size(), &m)) return 1;
+    std::vector<Slot> slots(4);
+    set_dense(slots[0], const_cast<float*>(d_in), cin1, D1, H1, W1);
+    if (d_in2) set_dense(slots[1], const_cast<float*>(d_in2), cin - cin1, D, H, W);
+    if (d_res) {
+        const int span = dil * (k - 1);
+        const int Ho = H + 2 * pad - span, Wo = W + 2 * pad - span, Do = dims == 3 ? D + 2 * pad - span : 1;
+        set_dense(slots[2], const_cast<float*>(d_res), cout, dims == 3 ? Do + 2 * res_crop : 1, Ho + 2 * res_crop,
+                  Wo + 2 * res_crop);
+    }
+    m->n_slots = 4;
+    m->last_use.assign(4, 0);
+    int rc = run_program(m, slots, d_out, nullptr);
+    if (rc == 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, "tpz_conv: kernel failed");
+    tpz_model_free(m);
+    return rc;
+}
+
+int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H, int W, float* d_out) {
+    if (!ctx || !d_in || !d_out) return fail(ctx, "tpz_maxpool2: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_maxpool2(d_in, d_out, C, D, H, W, dims, ctx->stream));
+    return 0;
+}
+
+int tpz_filter_2d(tpz_ctx* ctx, const float* d_in, int H, int W, const float* h_w, int k, float bias, float* d_out) {
+    if (!ctx || !d_in || !h_w || !d_out || k < 1 || (k & 1) == 0) return fail(ctx, "tpz_filter_2d: bad arguments");
+    return tpz_conv(ctx, 2, d_in, 1, 1, H, W, nullptr, 1, 1, H, W, h_w, &bias, 1, k, 1, k / 2, 1.0f, nullptr, 0, nullptr,
+                    nullptr, nullptr, 0.f, d_out);
+}
+
+// ---- NMS ------------------------------------------------------------------------------------------
+static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int dims, int r, const int* h_aux,
+                      int n_aux, float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n) {
+    const size_t n = (size_t)D * H * W;
+    if (n >= ((size_t)1 << 32)) return fail(ctx, "nms: more than 2^32 elements");
+    hipStream_t s = ctx->stream;
+    uint8_t* status = (uint8_t*)pool_alloc(ctx, n);
+    uint32_t* cand = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
+    int* d_aux = (int*)pool_alloc(ctx, std::max(1, n_aux) * sizeof(int));
+    if (!status || !cand || !d_aux) return fail(ctx, "nms: out of device memory");
+    int rc = 0;
+    uint64_t* keys = nullptr;
+    unsigned int hc[4] = {0, 0, 0, 0};
+    auto done = [&](int code) {
+        pool_release(ctx, status);
+        pool_release(ctx, cand);
+        pool_release(ctx, d_aux);
+        if (keys) pool_release(ctx, keys);
+        return code;
+    };
+    prof_begin(ctx, 3, 0);
+    if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned int), s) != hipSuccess ||
+        hipMemcpyAsync(d_aux, h_aux, n_aux * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+        nms_mark(d_score, n, threshold, status, cand, ctx->d_counters, s) != hipSuccess ||
+        hipMemcpyAsync(hc, ctx->d_counters, sizeof hc, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        prof_end(ctx);
+        return done(fail(ctx, "nms: mark phase failed: %s", hipGetErrorString(hipGetLastError())));
+    }
+    const unsigned int ncand = hc[0];
+    unsigned int npicks = 0;
+    if (ncand > 0) {
+        // relaxation sweeps until no candidate is undecided; every sweep decides at least the
+        // highest-priority undecided candidate, so ncand sweeps is a hard upper bound.
+        unsigned int remaining = ncand;
+        unsigned long long sweeps = 0;
+        while (remaining > 0) {
+            if (++sweeps > (unsigned long long)ncand + 1) { prof_end(ctx); return done(fail(ctx, "nms: fix-point did not converge")); }
+            hipError_t e = hipMemsetAsync(ctx->d_counters + 1, 0, sizeof(unsigned int), s);
+            if (e == hipSuccess)
+                e = dims == 2 ? nms2d_iter(d_score, H, W, r, d_aux, status, cand, ncand, ctx->d_counters, s)
+                              : nms3d_iter(d_score, (long long)n, d_aux, n_aux, status, cand, ncand, ctx->d_counters, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&remaining, ctx->d_counters + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: sweep failed: %s", hipGetErrorString(e))); }
+        }
+        size_t npow2 = 4096;
+        while (npow2 < ncand) npow2 <<= 1;
+        keys = (uint64_t*)pool_alloc(ctx, npow2 * sizeof(uint64_t));
+        if (!keys) { prof_end(ctx); return done(fail(ctx, "nms: out of device memory")); }
+        hipError_t e = nms_gather(d_score, status, cand, ncand, keys, ctx->d_counters, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&npicks, ctx->d_counters + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: gather failed: %s", hipGetErrorString(e))); }
+        size_t sp2 = 4096;
+        while (sp2 < npicks) sp2 <<= 1;
+        e = fill_u64(keys, npicks, sp2, 0ull, s);
+        if (e == hipSuccess) e = bitonic_sort_desc(keys, sp2, s);
+        const unsigned int nw = std::min<unsigned int>(npicks, (unsigned int)std::max(cap, 0));
+        if (e == hipSuccess) e = nms_write(keys, nw, d_score, H, W, dims, d_coords, d_scores, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: sort/write failed: %s", hipGetErrorString(e))); }
+    }
+    prof_end(ctx);
+    if (h_n) *h_n = (int)npicks;
+    if ((long long)npicks > (long long)cap) rc = fail(ctx, "nms: %u picks exceed the output capacity %d", npicks, cap);
+    return done(rc);
+}
+
+int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float threshold, int32_t* d_coords,
+               float* d_scores, int cap, int* h_n) {
+    if (!ctx || !d_score || H < 1 || W < 1 || r < 0) return fail(ctx, "tpz_nms_2d: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int> halfw(2 * r + 1);
+    for (int dy = -r; dy <= r; ++dy) {
+        int hw = (int)std::floor(std::sqrt((double)(r * r - dy * dy)));
+        while ((hw + 1) * (hw + 1) + dy * dy <= r * r) ++hw;
+        while (hw * hw + dy * dy > r * r) --hw;
+        halfw[dy + r] = hw;
+    }
+    return nms_common(ctx, d_score, 1, H, W, 2, r, halfw.data(), (int)halfw.size(), threshold, d_coords, d_scores, cap, h_n);
+}
+
+int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, float scale, float threshold,
+               int32_t* d_coords, float* d_scores, int cap, int* h_n) {
+    if (!ctx || !d_score || D < 1 || H < 1 || W < 1 || r < 0) return fail(ctx, "tpz_nms_3d: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // algorithms.py:68-79: r = scale*r (float), width = ceil(r), deltas over the ball
+    const double rr = (double)scale * (double)r;
+    const int width = (int)std::ceil(rr);
+    const long long zs = (long long)H * W, ys = W;
+    std::vector<int> deltas;
+    for (int ii = -width; ii <= width; ++ii)
+        for (int jj = -width; jj <= width; ++jj)
+            for (int kk = -width; kk <= width; ++kk)
+                if ((double)(ii * ii + jj * jj + kk * kk) <= rr * rr) {
+                    const long long dlt = ii * zs + jj * ys + kk;
+                    if (std::llabs(dlt) < ((long long)1 << 31)) deltas.push_back((int)dlt);
+                }
+    std::sort(deltas.begin(), deltas.end());
+    deltas.erase(std::unique(deltas.begin(), deltas.end()), deltas.end());
+    return nms_common(ctx, d_score, D, H, W, 3, r, deltas.data(), (int)deltas.size(), threshold, d_coords, d_scores, cap, h_n);
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+int tpz_prof_enable(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    prof_flush(ctx);
+    ctx->prof = on != 0;
+    return 0;
+}
+int tpz_prof_reset(tpz_ctx* ctx) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    prof_flush(ctx);
+    for (int i = 0; i < 4; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; ctx->acc_flops[i] = 0; }
+    return 0;
+}
+int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops) {
+    if (!ctx || cls < 0 || cls > 3) return fail(ctx, "tpz_prof_get: bad arguments");
+    prof_flush(ctx);
+    if (ms) *ms = ctx->acc_ms[cls];
+    if (launches) *launches = ctx->acc_n[cls];
+    if (flops) *flops = ctx->acc_flops[cls];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+"""Thin Python objects over the C-ABI: one Context per GPU, DeviceModel = a loaded layer program.
+
+PyTorch is used only as plumbing: device memory (tensors), the current HIP stream and
+torch.distributed.  All arithmetic of the hot path happens inside libtopaz_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TpzLayer, check, load_library
+
+_contexts = {}
+
+
+class Context:
+    """tpz_ctx for one device.  Use get_context(device) rather than constructing directly."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.TopazHipError('no HIP device visible: topaz_amd needs an MI355X (gfx950); there is no CPU path')
+        self.lib = load_library()
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self.lib.tpz_ctx_create(self.device, C.byref(h)))
+        self.handle = h
+        self._bound_stream = None
+
+    def bind_current_stream(self) -> None:
+        """run subsequent calls on torch's current stream for this device"""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound_stream:
+            check(self.lib.tpz_ctx_set_stream(self.handle, C.c_void_p(s)), self.handle)
+            self._bound_stream = s
+
+    def sync(self) -> None:
+        check(self.lib.tpz_ctx_sync(self.handle), self.handle)
+
+    def torch_device(self) -> torch.device:
+        return torch.device('cuda', self.device)
+
+    # ---- profiling counters (HIP events around every launch of a kernel class)
+    def prof_enable(self, on: bool = True) -> None:
+        check(self.lib.tpz_prof_enable(self.handle, 1 if on else 0), self.handle)
+
+    def prof_reset(self) -> None:
+        check(self.lib.tpz_prof_reset(self.handle), self.handle)
+
+    def prof_get(self, cls: int) -> Tuple[float, int, float]:
+        ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+        check(self.lib.tpz_prof_get(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)), self.handle)
+        return ms.value, n.value, fl.value
+
+
+def get_context(device: Optional[int] = None) -> Context:
+    if device is None or device < 0:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _contexts[device] = ctx
+    ctx.bind_current_stream()
+    return ctx
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def as_device_f32(x, ctx: Context) -> torch.Tensor:
+    """numpy / tensor -> contiguous fp32 tensor on the ctx device"""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=ctx.torch_device(), dtype=torch.float32).contiguous()
+
+
+class LayerProgram:
+    """Host-side builder of the tpz_layer list + weight blob (the model manifest)."""
+
+    def __init__(self, dims: int = 2):
+        self.dims = dims
+        self.layers: List[TpzLayer] = []
+        self.blob: List[np.ndarray] = []
+        self.n_floats = 0
+        self.n_slots = 1          # slot 0 = input
+
+    def new_slot(self) -> int:
+        s = self.n_slots
+        self.n_slots += 1
+        return s
+
+    def _push(self, a) -> int:
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).ravel())
+        off = self.n_floats
+        self.blob.append(a)
+        self.n_floats += a.size
+        return off
+
+    def conv(self, src: int, weight, bias=None, dil: int = 1, pad: int = 0, slope: float = 1.0, src2: int = -1,
+             res: int = -1, res_crop: int = 0, post_scale=None, post_shift=None, head_w=None, head_b=None,
+             dst: Optional[int] = None) -> int:
+        w = np.asarray(weight, dtype=np.float32)
+        cout, cin, k = w.shape[0], w.shape[1], w.shape[-1]
+        L = TpzLayer()
+        L.op = _lib.TPZ_OP_CONV
+        L.dims = self.dims
+        L.src, L.src2 = src, src2
+        L.dst = self.new_slot() if dst is None else dst
+        L.cin, L.cout, L.k, L.dil, L.pad = cin, cout, k, dil, pad
+        L.slope = float(slope)
+        L.w_off = self._push(w)
+        L.b_off = self._push(bias) if bias is not None else -1
+        L.res, L.res_crop = res, res_crop
+        if post_scale is not None:
+            L.post_scale_off = self._push(post_scale)
+            L.post_shift_off = self._push(post_shift)
+        else:
+            L.post_scale_off = L.post_shift_off = -1
+        if head_w is not None:
+            L.head = 1
+            L.head_w_off = self._push(head_w)
+            L.head_b_off = self._push(np.asarray([head_b], dtype=np.float32))
+        else:
+            L.head = 0
+            L.head_w_off = L.head_b_off = -1
+        self.layers.append(L)
+        return L.dst
+
+    def maxpool2(self, src: int) -> int:
+        L = TpzLayer()
+        L.op = _lib.TPZ_OP_MAXPOOL2
+        L.dims = self.dims
+        L.src, L.src2, L.res = src, -1, -1
+        L.dst = self.new_slot()
+        L.w_off = L.b_off = L.post_scale_off = L.post_shift_off = L.head_w_off = L.head_b_off = -1
+        L.slope = 1.0
+        self.layers.append(L)
+        return L.dst
+
+    def flat_blob(self) -> np.ndarray:
+        if not self.blob:
+            return np.zeros(1, dtype=np.float32)
+        return np.concatenate(self.blob).astype(np.float32, copy=False)
+
+
+class DeviceModel:
+    """tpz_model: weights packed into MFMA fragment order and resident in HBM."""
+
+    def __init__(self, program: LayerProgram, ctx: Optional[Context] = None):
+        self.ctx = ctx or get_context()
+        self.dims = program.dims
+        lib = self.ctx.lib
+        n = len(program.layers)
+        arr = (TpzLayer * n)(*program.layers)
+        blob = program.flat_blob()
+        h = C.c_void_p()
+        check(lib.tpz_model_load(self.ctx.handle, arr, n, blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(h)),
+              self.ctx.handle)
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.ctx.lib.tpz_model_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def out_shape(self, D: int, H: int, W: int) -> Tuple[int, int, int]:
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(self.ctx.lib.tpz_model_out_shape(self.handle, D, H, W, C.byref(a), C.byref(b), C.byref(c)),
+              self.ctx.handle)
+        return a.value, b.value, c.value
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [N,1,(D,)H,W] (or without the channel axis) on the ctx device -> [N,1,(Do,)Ho,Wo]"""
+        self.ctx.bind_current_stream()
+        nd = self.dims
+        if x.dim() == nd + 1:
+            x = x.unsqueeze(1)
+        if x.dim() != nd + 2 or x.shape[1] != 1:
+            raise ValueError(f'expected [N,1,{"D,H,W" if nd == 3 else "H,W"}] input, got {tuple(x.shape)}')
+        x = as_device_f32(x, self.ctx)
+        N = x.shape[0]
+        D = x.shape[2] if nd == 3 else 1
+        H, W = x.shape[-2], x.shape[-1]
+        Do, Ho, Wo = self.out_shape(D, H, W)
+        if min(Do, Ho, Wo) < 1:
+            raise ValueError(f'input {tuple(x.shape)} is too small for this model')
+        shape = (N, 1, Do, Ho, Wo) if nd == 3 else (N, 1, Ho, Wo)
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        check(self.ctx.lib.tpz_model_forward(self.handle, _ptr(x), N, D, H, W, _ptr(y)), self.ctx.handle)
+        return y
+
+    def denoise_2d(self, x: torch.Tensor, patch: int, pad: int) -> torch.Tensor:
+        self.ctx.bind_current_stream()
+        x = as_device_f32(x, self.ctx)
+        H, W = x.shape
+        y = torch.empty_like(x)
+        check(self.ctx.lib.tpz_denoise_2d(self.handle, _ptr(x), H, W, int(patch), int(pad), _ptr(y)), self.ctx.handle)
+        return y
+
+    def denoise_3d(self, x: torch.Tensor, patch: int, pad: int) -> torch.Tensor:
+        self.ctx.bind_current_stream()
+        x = as_device_f32(x, self.ctx)
+        D, H, W = x.shape
+        y = torch.empty_like(x)
+        check(self.ctx.lib.tpz_denoise_3d(self.handle, _ptr(x), D, H, W, int(patch), int(pad), _ptr(y)),
+              self.ctx.handle)
+        return y
+
+
+# ---- single ops ------------------------------------------------------------------------------------
+def conv(x: torch.Tensor, weight, bias=None, dil: int = 1, pad: int = 0, slope: float = 1.0,
+         x2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, res_crop: int = 0,
+         post_scale=None, post_shift=None, head_w=None, head_b: float = 0.0,
+         ctx: Optional[Context] = None) -> torch.Tensor:
+    """One fused convolution through tpz_conv.  x: [C1,(D1,)H1,W1]; x2 (optional, concatenated after the
+    nearest-upsampled x): [C2,(D,)H,W].  Returns [Cout,(Do,)Ho,Wo] (or [1,...] with a fused head)."""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
+    dims = w.ndim - 2
+    x = as_device_f32(x, ctx)
+    c1 = x.shape[0]
+    D1 = x.shape[1] if dims == 3 else 1
+    H1, W1 = x.shape[-2], x.shape[-1]
+    if x2 is not None:
+        x2 = as_device_f32(x2, ctx)
+        D = x2.shape[1] if dims == 3 else 1
+        H, W = x2.shape[-2], x2.shape[-1]
+        cin = c1 + x2.shape[0]
+    else:
+        D, H, W, cin = D1, H1, W1, c1
+    cout, k = w.shape[0], w.shape[-1]
+    assert w.shape[1] == cin, (w.shape, cin)
+    span = dil * (k - 1)
+    Do = D + 2 * pad - span if dims == 3 else 1
+    Ho, Wo = H + 2 * pad - span, W + 2 * pad - span
+    co = 1 if head_w is not None else cout
+    shape = (co, Do, Ho, Wo) if dims == 3 else (co, Ho, Wo)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+
+    def hp(a):
+        if a is None:
+            return None, C.c_void_p(None)
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    kb, pb = hp(bias)
+    ks, ps_ = hp(post_scale)
+    kt, pt = hp(post_shift)
+    kh, ph = hp(head_w)
+    if res is not None:
+        res = as_device_f32(res, ctx)
+    check(ctx.lib.tpz_conv(ctx.handle, dims, _ptr(x), c1, D1, H1, W1, _ptr(x2) if x2 is not None else C.c_void_p(None),
+                           cin, D, H, W, w.ctypes.data_as(C.c_void_p), pb, cout, k, dil, pad, float(slope),
+                           _ptr(res) if res is not None else C.c_void_p(None), res_crop, ps_, pt, ph, float(head_b),
+                           _ptr(y)), ctx.handle)
+    return y
+
+
+def maxpool2(x: torch.Tensor, ctx: Optional[Context] = None) -> torch.Tensor:
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    dims = x.dim() - 1
+    Cc = x.shape[0]
+    D = x.shape[1] if dims == 3 else 1
+    H, W = x.shape[-2], x.shape[-1]
+    shape = (Cc, D // 2, H // 2, W // 2) if dims == 3 else (Cc, H // 2, W // 2)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(ctx.lib.tpz_maxpool2(ctx.handle, dims, _ptr(x), Cc, D, H, W, _ptr(y)), ctx.handle)
+    return y
+
+
+def mean_std(x: torch.Tensor, unbiased: bool, ctx: Optional[Context] = None) -> Tuple[float, float]:
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    out = (C.c_float * 2)()
+    check(ctx.lib.tpz_mean_std(ctx.handle, _ptr(x), x.numel(), 1 if unbiased else 0, out), ctx.handle)
+    return float(out[0]), float(out[1])
+
+
+def affine(x: torch.Tensor, scale: float, shift: float, ctx: Optional[Context] = None) -> torch.Tensor:
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    y = torch.empty_like(x)
+    check(ctx.lib.tpz_affine(ctx.handle, _ptr(x), x.numel(), float(scale), float(shift), _ptr(y)), ctx.handle)
+    return y
+
+
+def filter_2d(x: torch.Tensor, w, bias: float = 0.0, ctx: Optional[Context] = None) -> torch.Tensor:
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    w = np.ascontiguousarray(np.asarray(w, dtype=np.float32))
+    H, W = x.shape
+    y = torch.empty_like(x)
+    check(ctx.lib.tpz_filter_2d(ctx.handle, _ptr(x), H, W, w.ctypes.data_as(C.c_void_p), w.shape[-1], float(bias),
+                                _ptr(y)), ctx.handle)
+    return y
+
+
+def nms(score: torch.Tensor, r: int, threshold: float, scale: float = 1.0, ctx: Optional[Context] = None,
+        cap: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """device NMS.  score [H,W] or [D,H,W]; returns (scores[n] fp32, coords[n,dims] int32 (x,y[,z])) on device"""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    score = as_device_f32(score, ctx)
+    dims = score.dim()
+    n_el = score.numel()
+    if cap is None:
+        # a pick suppresses at least itself; with r >= 1 picks are > r apart, so this bound is generous
+        cap = n_el if r < 1 else max(1024, min(n_el, (4 * n_el) // max(1, r * r) + 1024))
+    while True:
+        coords = torch.empty((cap, dims), dtype=torch.int32, device=score.device)
+        out = torch.empty((cap,), dtype=torch.float32, device=score.device)
+        n = C.c_int(0)
+        thr = float(threshold)
+        if thr == float('-inf'):
+            thr = -3.4028234663852886e38 * 2   # passes through c_float as -inf
+        if dims == 2:
+            H, W = score.shape
+            rc = ctx.lib.tpz_nms_2d(ctx.handle, _ptr(score), H, W, int(r), thr, _ptr(coords), _ptr(out), cap,
+                                    C.byref(n))
+        else:
+            D, H, W = score.shape
+            rc = ctx.lib.tpz_nms_3d(ctx.handle, _ptr(score), D, H, W, int(r), float(scale), thr, _ptr(coords),
+                                    _ptr(out), cap, C.byref(n))
+        if rc != 0 and n.value > cap:
+            cap = n.value          # capacity guess too small: rerun with the exact size
+            continue
+        check(rc, ctx.handle)
+        return out[:n.value], coords[:n.value]
