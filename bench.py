@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X hot path: micrographs/s, denoise -> score -> NMS on 4096x4096 fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pipeline|extract|denoise]
+
+One step = one synthetic 4096x4096 micrograph (N(0,1), seed 1000+i, already resident in HBM)
+through the whole path on one GPU:
+    U-Net denoise   `topaz denoise -m unet` architecture (UDenoiseNet base 11 / top 5, nf 48) with the
+                    CLI-default patching -s 1024 -p 500 (16 patches, 50.4 Mpx), per-patch normalisation
+    ResNet8 score   `topaz extract -m resnet8` architecture (units 64), filled, head fused
+    NMS             radius 14, threshold -6  -> pick table
+The pretrained blobs of both default architectures are absent upstream, so
+the weights are seeded random (calibrated to realistic logit statistics) -- the arithmetic and the
+shapes are those of the named configs.  Multi-GPU (torchrun): every rank processes its own K images
+(weak scaling), then the pick tables are gathered to rank 0 over RCCL (the only collective).
+
+Prints ONE JSON line (see the driver contract) including
+  roofline     -- the dominant kernel class (conv_mfma, fp32 matrix cores): algorithmic FLOP / HIP-event
+                  time of those launches, measured live in a separate profiled step after the timed region
+  cpu_baseline -- the oracle (CPU restatement of the reference, torch-CPU) timed on a bounded sample of
+                  the same workload on this host, rank 0 and N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def build_models(workload: str):
+    from oracle import denoising as oden          # seeded-weight generators only (not on the timed path)
+    from oracle import scoring as oscoring
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    from topaz_amd.model.classifier import LinearClassifier
+    out = {}
+    if workload in ('pipeline', 'denoise'):
+        sd_d = oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)
+        out['denoise'] = (Denoise(DenoiseNet('unet', sd_d)), sd_d)
+    if workload in ('pipeline', 'extract'):
+        sd_s = oscoring.synthetic_resnet_sd('resnet8', 64, seed=7)
+        m = LinearClassifier('resnet8', sd_s)
+        m.eval(); m.fill(); m.cuda()
+        out['score'] = (m, sd_s)
+    return out
+
+
+def run_step(models, x_dev, args):
+    """one micrograph through the path; returns the pick table (device tensors)"""
+    from topaz_amd import runtime as rt
+    img = x_dev
+    if 'denoise' in models:
+        img = models['denoise'][0].denoise_device(img, args.patch_size, args.patch_padding)
+    if 'score' in models:
+        logits = models['score'][0](img[None, None])[0, 0]
+        return rt.nms(logits, args.radius, args.threshold)
+    return img, None
+
+
+def cpu_baseline(models, args):
+    """oracle timed on a bounded sample: a SxS crop of micrograph 0 through the same stages; scaled to
+    micrographs/s by the pixel counts the full workload processes (patched denoising touches 3.0x the
+    image)."""
+    from oracle import denoising as oden
+    from oracle import nms as onms
+    from oracle import scoring as oscoring
+    S = args.cpu_sample
+    x = np.random.RandomState(1000).randn(S, S).astype(np.float32)
+    threads = torch.get_num_threads()
+    per_image = 0.0
+    parts = {}
+    full_px = float(args.size) ** 2
+    if 'denoise' in models:
+        sd = models['denoise'][1]
+        t0 = time.time(); den = oden.denoise('unet', sd, x, -1); t = time.time() - t0
+        # pixels the full job pushes through the net with -s/-p patching
+        n_px = 0
+        for i in range(0, args.size, args.patch_size):
+            for j in range(0, args.size, args.patch_size):
+                h = min(args.size, i + args.patch_size + args.patch_padding) - max(0, i - args.patch_padding)
+                w = min(args.size, j + args.patch_size + args.patch_padding) - max(0, j - args.patch_padding)
+                n_px += h * w
+        parts['denoise_s'] = t
+        per_image += t * n_px / (S * S)
+        x = den
+    if 'score' in models:
+        sd = models['score'][1]
+        t0 = time.time(); logit = oscoring.score('resnet8', sd, x); t = time.time() - t0
+        parts['score_s'] = t
+        per_image += t * full_px / (S * S)
+        t0 = time.time(); onms.nms2d(logit, args.radius, args.threshold); t = time.time() - t0
+        parts['nms_s'] = t
+        per_image += t * full_px / (S * S)
+    return {'value': 1.0 / per_image, 'unit': 'micrographs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{S}x{S} crop of micrograph 0 through the oracle (torch-CPU convs, C NMS), '
+                      f'times {parts} scaled by processed-pixel ratio to {args.size}x{args.size}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='pipeline', choices=['pipeline', 'extract', 'denoise'])
+    ap.add_argument('--size', type=int, default=4096)
+    ap.add_argument('--patch-size', type=int, default=1024)
+    ap.add_argument('--patch-padding', type=int, default=500)
+    ap.add_argument('--radius', type=int, default=14)
+    ap.add_argument('--threshold', type=float, default=-6.0)
+    ap.add_argument('--cpu-sample', type=int, default=768)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from topaz_amd import parallel
+    rank, local_rank, world = parallel.init_from_env()
+    assert world == args.gpus or world == 1, f'WORLD_SIZE={world} but --gpus {args.gpus}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    from topaz_amd.runtime import get_context
+    ctx = get_context(local_rank)
+
+    models = build_models(args.workload)
+    n_img = args.steps + args.warmup
+    # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world)
+    imgs = [torch.from_numpy(np.random.RandomState(1000 + rank + i * world).randn(args.size, args.size)
+                             .astype(np.float32)).to(dev) for i in range(n_img)]
+
+    for i in range(args.warmup):
+        run_step(models, imgs[i], args)
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    t0 = time.perf_counter()
+    ids, scs, cds = [], [], []
+    for i in range(args.warmup, n_img):
+        s, c = run_step(models, imgs[i], args)
+        if c is not None:
+            ids.append(rank + i * world); scs.append(s); cds.append(c)
+    if ids and world > 1:
+        parallel.gather_pick_tables(ids, scs, cds, dev)       # the one RCCL exchange step
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    n_picks = int(sum(int(s.numel()) for s in scs)) if scs else 0
+
+    # ---- roofline of the dominant kernel class, measured live with HIP events on the kernel's stream
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    run_step(models, imgs[-1], args)
+    torch.cuda.synchronize(dev)
+    conv_ms, conv_n, conv_flops = ctx.prof_get(0)
+    other = {name: ctx.prof_get(k)[0] for k, name in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms'))}
+    ctx.prof_enable(False)
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            'metric': 'micrographs/sec (4096x4096 fp32) denoise+score, NMS parity',
+            'value': world * args.steps / dt,
+            'unit': 'micrographs/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic (N(0,1) micrographs seed 1000+i; seeded random weights of the named architectures)',
+            'config': {
+                'workload': {'pipeline': 'denoise(unet b11/t5 nf48, -s 1024 -p 500) -> score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
+                             'extract': 'score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
+                             'denoise': 'denoise(unet b11/t5 nf48, -s 1024 -p 500)'}[args.workload],
+                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps,
+                'parallelism': f'one micrograph per rank x{world}; RCCL gather of pick tables',
+                'picks_per_image': n_picks / max(1, len(scs)) if scs else None,
+            },
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'conv_mfma_kernel (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM conv)',
+                'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'launches_per_step': conv_n, 'algorithmic_tflop_per_step': conv_flops / 1e12,
+                'kernel_ms_per_step': conv_ms, 'avg_launch_ms': conv_ms / max(1, conv_n), **other,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(models, args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -80,6 +80,7 @@ def scoring():
     torch.manual_seed(7)
     m = LinearClassifier(ResNet8(units=16, bn=True))
     randomise_bn(m, 8)
+    torch.save(m, os.path.join(OUT, 'user_model_resnet8_bn_u16.sav'))   # what `topaz train` writes (training.py:601)
     x = image(3, 120, 136)
     save('score_resnet8_bn_u16', arch=np.asarray('resnet8'), x0=x, y0=run(m, x), **sd_arrays(m))
 
@@ -94,6 +95,7 @@ def scoring():
     for p in m.modules():
         if isinstance(p, torch.nn.PReLU):
             p.weight.data.uniform_(0.1, 0.4)
+    torch.save(m, os.path.join(OUT, 'user_model_conv127_bn_u16.sav'))
     x = image(5, 140, 150)
     save('score_conv127_bn_u16', arch=np.asarray('conv127'), x0=x, y0=run(m, x), **sd_arrays(m))
 
@@ -208,6 +210,7 @@ def denoise2d():
     net = UDenoiseNet(nf=16, base_width=11, top_width=5)
     dn = Denoise.__new__(Denoise)
     dn.model, dn.device, dn.dims, dn.use_cuda = net.eval(), torch.device('cpu'), 2, False
+    torch.save(net, os.path.join(OUT, 'user_model_unet_b11t5_nf16.sav'))   # denoising/models.py:628-633 save_model
     x2 = image(32, 110, 121)
     save('denoise2d_unet_b11t5_nf16', x=x2, whole=dn.denoise(x2, patch_size=-1), p48_20=dn.denoise(x2, 48, 20),
          **sd_arrays(net))

@@ -200,7 +200,13 @@ def synthetic_resnet_sd(arch: str, units: int, seed: int, bn: bool = False) -> '
             if bn:
                 bnorm(pre + 'bn1', co)
     sd['classifier.weight'] = (rs.randn(1, u[2], 1, 1) * np.sqrt(1.0 / u[2])).astype(np.float32)
-    sd['classifier.bias'] = np.asarray([-2.0], dtype=np.float32)
+    sd['classifier.bias'] = np.asarray([0.0], dtype=np.float32)
+    # calibrate the head so logits on N(0,1) input look like the pretrained nets' (std ~4, mean ~-8,
+    # range about [-20, +5]): the 1e-4 absolute tolerance of BASELINE.json is stated for that range.
+    probe = np.random.RandomState(seed + 1).randn(64, 64).astype(np.float32)
+    y = score(arch, sd, probe)
+    sd['classifier.weight'] = (sd['classifier.weight'] * (4.0 / max(float(y.std()), 1e-6))).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([-8.0 - float(y.mean()) * 4.0 / max(float(y.std()), 1e-6)], dtype=np.float32)
     return sd
 
 

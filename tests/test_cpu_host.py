@@ -1,0 +1,116 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol,
+the ctypes struct matches the header, the packers emit the right graphs, model files parse."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_sd, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from topaz_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'topaz_hip.h')).read()
+    declared = set(re.findall(r'\b(tpz_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no prototypes found in the header'
+    lib = C.CDLL(_lib.LIB_PATH)                       # raw dlopen: no GPU needed
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/topaz_hip.h but not exported'
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    _lib.load_library()                               # prototypes attach without error
+
+
+def test_layer_struct_matches_header():
+    from topaz_amd._lib import TpzLayer
+    header = open(os.path.join(ROOT, 'include', 'topaz_hip.h')).read()
+    body = header[header.index('typedef struct tpz_layer {'):header.index('} tpz_layer;')]
+    fields = re.findall(r'^\s*(int32_t|int64_t|float)\s+([a-z0-9_]+);', body, flags=re.M)
+    ctype = {'int32_t': C.c_int32, 'int64_t': C.c_int64, 'float': C.c_float}
+    assert [(n, ctype[t]) for t, n in fields] == list(TpzLayer._fields_)
+    assert C.sizeof(TpzLayer) % 8 == 0
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible')
+    from topaz_amd import runtime, _lib
+    with pytest.raises(_lib.TopazHipError):
+        runtime.get_context(0)
+    lib = _lib.load_library()
+    h = C.c_void_p()
+    assert lib.tpz_ctx_create(0, C.byref(h)) != 0
+    assert b'no HIP device' in lib.tpz_last_error(None)
+
+
+def test_resnet_packer_graph():
+    from topaz_amd.model import pack
+    from oracle.scoring import synthetic_resnet_sd
+    P, width = pack.pack_resnet('resnet8', synthetic_resnet_sd('resnet8', 32, 1))
+    assert width == 71
+    convs = [(L.k, L.dil, L.cin, L.cout, L.pad, L.res_crop, L.head) for L in P.layers]
+    assert convs == [(7, 1, 1, 32, 35, 0, 0),
+                     (3, 2, 32, 32, 0, 0, 0), (3, 4, 32, 32, 0, 6, 0),
+                     (3, 2, 32, 32, 0, 0, 0), (1, 1, 32, 64, 0, 0, 0), (3, 4, 32, 64, 0, 6, 0),
+                     (3, 4, 64, 64, 0, 0, 0), (3, 8, 64, 64, 0, 12, 0),
+                     (5, 4, 64, 128, 0, 0, 1)]
+    P16, w16 = pack.pack_resnet('resnet16', synthetic_resnet_sd('resnet16', 16, 2, bn=True))
+    assert w16 == 91
+    dils = [L.dil for L in P16.layers if L.k == 3]
+    assert dils == [1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 4, 4, 4, 4]
+    assert sum(1 for L in P16.layers if L.post_scale_off >= 0) == 7     # bn1 kept as an epilogue affine
+
+
+def test_bn_folding_matches_oracle_arithmetic():
+    from topaz_amd.model import pack
+    rs = np.random.RandomState(0)
+    w, b = rs.randn(8, 4, 3, 3).astype(np.float32), None
+    sd = {'bn.weight': rs.rand(8).astype(np.float32) + .5, 'bn.bias': rs.randn(8).astype(np.float32),
+          'bn.running_mean': rs.randn(8).astype(np.float32), 'bn.running_var': rs.rand(8).astype(np.float32) + .5}
+    w2, b2 = pack._fold_bn(w, b, sd, 'bn')
+    import torch
+    import torch.nn.functional as F
+    x = torch.randn(1, 4, 9, 9)
+    ref = F.batch_norm(F.conv2d(x, torch.from_numpy(w)), torch.from_numpy(sd['bn.running_mean']),
+                       torch.from_numpy(sd['bn.running_var']), torch.from_numpy(sd['bn.weight']),
+                       torch.from_numpy(sd['bn.bias']), False, 0.0, 1e-5)
+    got = F.conv2d(x, torch.from_numpy(w2), torch.from_numpy(b2))
+    assert (ref - got).abs().max() < 1e-5
+
+
+def test_unet_packer_graph():
+    from topaz_amd.model import pack
+    from oracle.denoising import synthetic_unet_sd
+    P = pack.pack_unet(synthetic_unet_sd(1, nf=48, base_width=11, top_width=5), 5, 2)
+    convs = [(L.cin, L.cout, L.k, L.src2 >= 0) for L in P.layers if L.op == 1]
+    assert convs[0] == (1, 48, 11, False) and convs[-1] == (32, 1, 5, False)
+    assert [c for c in convs if c[3]] == [(96, 96, 3, True), (144, 96, 3, True), (144, 96, 3, True),
+                                          (144, 96, 3, True), (97, 64, 5, True)]
+    assert sum(1 for L in P.layers if L.op == 2) == 5
+
+
+@pytest.mark.parametrize('name,arch', [('resnet8_bn_u16', 'resnet8'), ('conv127_bn_u16', 'conv127')])
+def test_user_model_pickle_parses_without_reference(name, arch):
+    import sys
+    assert 'topaz' not in sys.modules
+    from topaz_amd.model.unpickle import load_module_pickle
+    a, sd = load_module_pickle(os.path.join(GOLDEN, f'user_model_{name}.sav'))
+    assert a == arch
+    want = golden_sd(load_golden(f'score_{name}'))
+    assert set(sd) == set(want)
+    for k in want:
+        assert np.array_equal(sd[k].numpy(), want[k]), k
+
+
+def test_patch_geometry_helpers():
+    import torch
+    from topaz_amd.model.utils import get_patches, reconstruct_from_patches, insize_from_outsize
+    X = torch.arange(1, 1 + 50 * 70, dtype=torch.float32).reshape(1, 1, 50, 70)
+    pad, size = 5, 30
+    patches = get_patches(X, size, pad)
+    assert len(patches) == 3 * 4 and patches[0].shape[-2:] == (30, 30)
+    cropped = [p[0, 0, pad:-pad, pad:-pad].numpy() for p in patches]
+    assert np.array_equal(reconstruct_from_patches(cropped, X.shape, size, pad)[0, 0], X[0, 0].numpy())
+    assert insize_from_outsize([dict(kernel_size=7, stride=2), dict(kernel_size=5)], 1) == 15

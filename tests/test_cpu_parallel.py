@@ -1,0 +1,76 @@
+"""world_size-2 gloo test of the multi-GPU layer (sharding + the pick-table gather)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tables(image_id):
+    rs = np.random.RandomState(100 + image_id)
+    n = int(rs.randint(0, 40))
+    s = torch.from_numpy(np.sort(rs.randn(n).astype(np.float32))[::-1].copy())
+    c = torch.from_numpy(rs.randint(0, 4096, size=(n, 2)).astype(np.int32))
+    return s, c
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from topaz_amd import parallel
+    r, lr, w = parallel.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    mine = parallel.shard_indices(n_images, rank, world)
+    tabs = [_tables(i) for i in mine]
+    dev = torch.device('cpu')
+    parallel.barrier(dev)
+    t = parallel.max_over_ranks(float(rank + 1), dev)
+    assert t == float(world)
+    out = parallel.gather_pick_tables(mine, [a for a, _ in tabs], [b for _, b in tabs], dev)
+    if rank == 0:
+        ok = sorted(out) == list(range(n_images))
+        for i in range(n_images):
+            s, c = _tables(i)
+            ok = ok and torch.equal(out[i][0], s) and torch.equal(out[i][1], c)
+        q.put(ok)
+    else:
+        assert out is None
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_indices_cover_everything():
+    from topaz_amd.parallel import shard_indices
+    for n in (0, 1, 7, 256):
+        for w in (1, 2, 8):
+            got = sorted(i for r in range(w) for i in shard_indices(n, r, w))
+            assert got == list(range(n))
+    assert shard_indices(256, 3, 8)[:3] == [3, 11, 19] and len(shard_indices(256, 3, 8)) == 32
+
+
+def test_gather_pick_tables_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_gather_single_process():
+    from topaz_amd.parallel import gather_pick_tables
+    s, c = _tables(3)
+    out = gather_pick_tables([3], [s], [c], torch.device('cpu'))
+    assert torch.equal(out[3][0], s) and torch.equal(out[3][1], c)

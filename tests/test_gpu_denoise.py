@@ -1,0 +1,79 @@
+"""U-Net / FCNN / affine denoising on the MI355X against the reference's golden outputs and the
+CPU oracle.  Tolerance 1e-4 on pixels of normalised scale (inputs here are x*3+10, so the
+comparison is done on (y-10)/3)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_sd, load_golden
+from oracle import denoising as oden
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _err(a, b, scale=1.0):
+    return np.abs(a - b).max() / scale
+
+
+@pytest.mark.parametrize('name', ['unet-v0.2.1', 'unet-small', 'affine'])
+def test_pretrained_vs_reference_golden(gpu_ctx, name):
+    from topaz_amd.denoise import Denoise
+    z = load_golden('denoise2d_pretrained')
+    d = Denoise(name)
+    x = z['x']
+    assert _err(d.denoise(x, patch_size=-1), z[f'{name}:whole'], 3.0) <= ATOL
+    assert _err(d.denoise(x, patch_size=64, padding=24), z[f'{name}:p64_24'], 3.0) <= ATOL
+
+
+def test_denoise_image_variants_vs_reference_golden(gpu_ctx):
+    from topaz_amd.denoise import Denoise, denoise_image
+    from topaz_amd.filters import GaussianDenoise
+    z = load_golden('denoise2d_pretrained')
+    x = z['x']
+    d = Denoise('unet-v0.2.1')
+    assert _err(denoise_image(x.copy(), [d], patch_size=96, padding=16), z['image:unet-v0.2.1:p96_16'], 3.0) <= ATOL
+    assert _err(denoise_image(x.copy(), [d], patch_size=-1, normalize=True), z['image:unet-v0.2.1:norm']) <= ATOL
+    g = GaussianDenoise(1.2)
+    assert _err(g.apply(x), z['gaus1.2:apply'], 3.0) <= ATOL
+    assert _err(denoise_image(x.copy(), [Denoise('unet-small')], gaus=g), z['image:unet-small:gaus1.2'], 3.0) <= ATOL
+    assert _err(denoise_image(x.copy(), [Denoise('affine')], cutoff=1.5), z['image:affine:cutoff'], 3.0) <= ATOL
+
+
+def test_seeded_v022_arch_vs_reference_golden(gpu_ctx):
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    z = load_golden('denoise2d_unet_b11t5_nf16')
+    d = Denoise(DenoiseNet('unet', golden_sd(z)))
+    assert _err(d.denoise(z['x'], -1), z['whole']) <= ATOL
+    assert _err(d.denoise(z['x'], 48, 20), z['p48_20']) <= ATOL
+
+
+def test_unet_v022_nf48_vs_oracle(gpu_ctx):
+    """the CLI-default architecture (base 11, top 5, nf 48; blob missing upstream), seeded weights,
+    odd pooled sizes (381 -> 190 -> 95 -> 47 -> 23 -> 11) and default-style patching"""
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)
+    x = np.random.RandomState(1002).randn(381, 400).astype(np.float32)
+    d = Denoise(DenoiseNet('unet', sd))
+    assert _err(d.denoise(x, -1), oden.denoise('unet', sd, x, -1)) <= ATOL
+    assert _err(d.denoise(x, 128, 60), oden.denoise('unet', sd, x, 128, 60)) <= ATOL
+
+
+def test_denoise3d_vs_reference_golden(gpu_ctx):
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    z = load_golden('denoise3d_unet3d_nf8')
+    d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+    assert _err(d.denoise(z['tomo'], 32, 16, verbose=False), z['p32_16'], 2.0) <= ATOL
+    assert _err(d.denoise(z['small'], -1, verbose=False), z['small_whole'], 2.0) <= ATOL
+
+
+def test_user_model_pickle(gpu_ctx):
+    import os
+    from conftest import GOLDEN
+    from topaz_amd.denoise import Denoise
+    z = load_golden('denoise2d_unet_b11t5_nf16')
+    d = Denoise(os.path.join(GOLDEN, 'user_model_unet_b11t5_nf16.sav'))
+    assert _err(d.denoise(z['x'], 48, 20), z['p48_20']) <= ATOL

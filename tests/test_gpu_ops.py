@@ -1,0 +1,133 @@
+"""Single HIP ops through the C-ABI against torch-CPU fp32 references of the same op.
+Tolerance: fp32 MFMA is an exact fmaf chain; differences to MKLDNN are summation-order round-off,
+bounded here by 1e-4 * (1 + |ref|) as SURVEY/BASELINE require for scores and pixels (1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, atol=1e-4):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b) / (1.0 + np.abs(b))
+    assert err.max() <= atol, f'max scaled err {err.max():.3e}'
+
+
+def _act(y, slope):
+    return torch.where(y > 0, y, y * slope)
+
+
+CONV_CASES = [
+    # cin, cout, k, dil, pad, H, W, slope
+    (32, 32, 3, 2, 0, 70, 90, 0.0),
+    (32, 64, 3, 4, 0, 61, 75, 0.0),
+    (64, 64, 3, 8, 0, 80, 81, 0.0),
+    (64, 128, 5, 4, 0, 50, 66, 0.0),
+    (128, 256, 5, 4, 0, 40, 49, 0.0),      # two co-groups of 128
+    (48, 48, 3, 1, 1, 45, 47, 0.1),
+    (96, 96, 3, 1, 1, 33, 65, 0.1),
+    (144, 96, 3, 1, 1, 30, 31, 0.1),       # cin not a multiple of the 8-channel chunk? (144 = 18*8)
+    (97, 64, 5, 1, 2, 37, 40, 0.1),        # odd cin -> zero-padded k-group
+    (64, 32, 5, 1, 2, 64, 70, 0.1),
+    (1, 32, 7, 1, 35, 40, 50, 0.0),        # CIN1 stem with the ResNet zero pad
+    (1, 48, 11, 1, 5, 50, 45, 0.1),        # CIN1 U-Net stem
+    (1, 48, 7, 1, 3, 31, 33, 0.1),
+    (32, 64, 1, 1, 0, 33, 47, 1.0),        # 1x1 projection
+    (32, 1, 5, 1, 2, 40, 41, 1.0),         # direct kernel (cout = 1)
+    (1, 1, 31, 1, 15, 50, 60, 1.0),        # affine / gaussian filter
+    (16, 16, 5, 16, 0, 90, 100, 0.25),     # conv127 last layer, PReLU slope
+    (16, 24, 3, 1, 1, 20, 20, 0.1),        # cout not a multiple of 16
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(gpu_ctx, case):
+    from topaz_amd import runtime as rt
+    cin, cout, k, dil, pad, H, W, slope = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    ref = _act(F.conv2d(x[None], w, b, dilation=dil, padding=pad)[0], slope)
+    y = rt.conv(x, w.numpy(), b.numpy(), dil=dil, pad=pad, slope=slope)
+    _close(y, ref)
+
+
+def test_conv2d_residual_bn_epilogue(gpu_ctx):
+    from topaz_amd import runtime as rt
+    g = torch.Generator().manual_seed(3)
+    cin, cout, H, W, d0, d1 = 32, 64, 60, 64, 2, 4
+    x = torch.randn(cin, H, W, generator=g)
+    t = torch.randn(cin, H - 2 * d0, W - 2 * d0, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 17.0
+    proj = torch.randn(cout, H, W, generator=g)              # stands for proj(x), uncropped
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    e = d0 + d1
+    ref = F.conv2d(t[None], w, None, dilation=d1)[0] + proj[:, e:-e, e:-e]
+    ref = F.relu(ref * scale[:, None, None] + shift[:, None, None])
+    y = rt.conv(t, w.numpy(), None, dil=d1, slope=0.0, res=proj, res_crop=e, post_scale=scale.numpy(),
+                post_shift=shift.numpy())
+    _close(y, ref)
+
+
+@pytest.mark.parametrize('cout', [128, 256])
+def test_conv2d_fused_head(gpu_ctx, cout):
+    from topaz_amd import runtime as rt
+    g = torch.Generator().manual_seed(4)
+    cin, H, W = 64, 50, 70
+    x = torch.randn(cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 5, 5, generator=g) / 40.0
+    b = torch.randn(cout, generator=g)
+    hw = torch.randn(cout, generator=g) / 11.0
+    feat = F.relu(F.conv2d(x[None], w, b, dilation=4))
+    ref = F.conv2d(feat, hw.view(1, cout, 1, 1), torch.tensor([-1.5]))[0]
+    y = rt.conv(x, w.numpy(), b.numpy(), dil=4, slope=0.0, head_w=hw.numpy(), head_b=-1.5)
+    _close(y, ref)
+
+
+@pytest.mark.parametrize('shape', [((48, 23, 31), (47, 63)), ((96, 16, 16), (32, 32)), ((20, 9, 7), (19, 15))])
+def test_conv2d_fused_upsample_concat(gpu_ctx, shape):
+    """F.interpolate(h, size, 'nearest') + torch.cat([h, skip]) folded into the conv's loader
+    (denoising/models.py:140-171), including the odd sizes where src != dst//2."""
+    from topaz_amd import runtime as rt
+    (c1, h1, w1), (H, W) = shape
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn(c1, h1, w1, generator=g)
+    skip = torch.randn(c1 // 2 + 1, H, W, generator=g)
+    cin = c1 + skip.shape[0]
+    w = torch.randn(32, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(32, generator=g)
+    cat = torch.cat([F.interpolate(h[None], size=(H, W), mode='nearest'), skip[None]], 1)
+    ref = F.leaky_relu(F.conv2d(cat, w, b, padding=1), 0.1)[0]
+    y = rt.conv(h, w.numpy(), b.numpy(), pad=1, slope=0.1, x2=skip)
+    _close(y, ref)
+
+
+@pytest.mark.parametrize('shape', [(48, 37, 41), (3, 2, 2), (5, 64, 65)])
+def test_maxpool2(gpu_ctx, shape):
+    from topaz_amd import runtime as rt
+    x = torch.randn(*shape)
+    y = rt.maxpool2(x)
+    assert torch.equal(y.cpu(), F.max_pool2d(x[None], 2)[0])
+
+
+def test_mean_std(gpu_ctx):
+    from topaz_amd import runtime as rt
+    x = torch.randn(1237, 911) * 3 + 100
+    m, s = rt.mean_std(x, unbiased=True)
+    assert abs(m - x.double().mean().item()) < 1e-4 and abs(s - x.double().std().item()) < 1e-5
+    m, s = rt.mean_std(x, unbiased=False)
+    assert abs(s - x.numpy().astype(np.float64).std()) < 1e-5
+
+
+def test_filter_2d_gaussian(gpu_ctx):
+    from oracle.denoising import gaussian_kernel
+    from topaz_amd import runtime as rt
+    f = gaussian_kernel(1.2)
+    x = torch.randn(90, 77)
+    ref = F.conv2d(x[None, None], torch.from_numpy(f)[None, None], padding=f.shape[0] // 2)[0, 0]
+    _close(rt.filter_2d(x, f), ref, atol=1e-5)

@@ -1,0 +1,104 @@
+"""Multi-GPU layer: micrographs shard embarrassingly (one image per rank at a time, rank r takes
+images i = r (mod world)); the only exchange step is the gather of the per-image pick tables to
+rank 0 for the single-TSV output mode of `topaz extract` (topaz/extract.py:321-354).
+
+One process per GPU; torch.distributed backend 'nccl' (= RCCL over xGMI on ROCm) on the GPU box,
+'gloo' in the CPU tests.  The reference has no distributed code; this is new.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world).  Single process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """items processed by `rank`: i = rank (mod world), in input order"""
+    return list(range(rank, n_items, world))
+
+
+def barrier(device: Optional[torch.device] = None) -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if device is not None and device.type == 'cuda':
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor], coords: Sequence[torch.Tensor],
+                       device: torch.device, dst: int = 0):
+    """Gather per-image pick tables to rank `dst`.
+
+    Every rank passes the images it owns: ids, scores[i] (fp32 [n_i]) and coords[i] (int32 [n_i, d]).
+    Exchange: one all_gather of (image count, row count) per rank, then one gather of the
+    concatenated (id, n) headers and one of the (x, y[, z], score-bits) rows, padded to the largest
+    rank.  Rows are a few hundred KB per micrograph, so the step is latency-bound; each peer writes to
+    the root over its own xGMI link.  Returns on dst a dict id -> (scores, coords) (CPU tensors), on
+    the other ranks None.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    d = coords[0].shape[1] if len(coords) else 2
+    if world == 1:
+        return {int(i): (s.cpu(), c.cpu()) for i, s, c in zip(image_ids, scores, coords)}
+    n_img = len(image_ids)
+    n_rows = int(sum(int(s.numel()) for s in scores))
+    meta = torch.tensor([n_img, n_rows, d], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    max_img = max(int(m[0]) for m in metas)
+    max_rows = max(int(m[1]) for m in metas)
+    d = max(int(m[2]) for m in metas)
+    head = torch.zeros((max(max_img, 1), 2), dtype=torch.int64, device=device)
+    for k, (i, s) in enumerate(zip(image_ids, scores)):
+        head[k, 0], head[k, 1] = int(i), int(s.numel())
+    rows = torch.zeros((max(max_rows, 1), d + 1), dtype=torch.int32, device=device)
+    if n_rows:
+        cat_c = torch.cat([c.to(device=device, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
+        cat_s = torch.cat([s.to(device=device, dtype=torch.float32).reshape(-1) for s in scores], 0)
+        rows[:n_rows, :d] = cat_c
+        rows[:n_rows, d] = cat_s.view(torch.int32)          # bit-exact transport of the fp32 scores
+    heads = [torch.zeros_like(head) for _ in range(world)] if rank == dst else None
+    rowss = [torch.zeros_like(rows) for _ in range(world)] if rank == dst else None
+    dist.gather(head, heads, dst=dst)
+    dist.gather(rows, rowss, dst=dst)
+    if rank != dst:
+        return None
+    out = {}
+    for r in range(world):
+        h, rw = heads[r].cpu(), rowss[r].cpu()
+        off = 0
+        for k in range(int(metas[r][0])):
+            iid, n = int(h[k, 0]), int(h[k, 1])
+            blk = rw[off:off + n]
+            out[iid] = (blk[:, d].contiguous().view(torch.float32).clone(), blk[:, :d].clone())
+            off += n
+    return out
