@@ -90,6 +90,8 @@ void tpz_model_free(tpz_model* m);
 int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out);
 /* output size of the model for a given input size */
 int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int* Wo);
+/* channels of the model output (1 for every network of the reference; >1 only for partial programs) */
+int tpz_model_out_channels(tpz_model* m, int* C);
 
 /* ---- denoising ----------------------------------------------------------------------- */
 /* replaces Denoise.denoise / denoise_patches / _denoise (topaz/denoise.py:274-332):

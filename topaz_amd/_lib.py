@@ -44,6 +44,7 @@ _SIGNATURES = {
     'tpz_model_forward': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_model_out_shape': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
+    'tpz_model_out_channels': (C.c_int, [_P, C.POINTER(C.c_int)]),
     'tpz_denoise_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_denoise_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_mean_std': (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),

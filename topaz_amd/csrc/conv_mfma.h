@@ -3,20 +3,23 @@
 // Replaces the torch.nn.Conv2d / Conv3d calls the reference issues on its hot path
 // (topaz/model/features/resnet.py:129-133,294-302, topaz/model/features/basic.py:47-63,
 //  topaz/denoising/models.py:79-128,457-512): dilated "valid" convs of the filled scoring
-// nets and "same" convs of the U-Nets, with the bias / activation / residual / eval-BN
-// epilogue fused (resnet.py:101-105,185-202).
+// nets and "same" convs of the U-Nets, with the bias / activation / residual / eval-BN /
+// 1x1-head epilogue fused (resnet.py:101-105,185-202, classifier.py:64-66) and the
+// nearest-upsample + concat of the U-Net decoders folded into the loader (models.py:140-171).
 //
 // GEMM view: M = output channels, N = output pixels, K = Cin * taps.
 //   one MFMA: A[16 co][4 k] * B[4 k][16 px] -> C[16 co][16 px], exact f32 (fmaf chain).
 //   k-group of 4 = four consecutive input channels at one tap            (generic)
 //                = four consecutive kx taps of the single input channel  (CIN1 stems)
-// Workgroup = 256 threads = 4 waves; tile = MT output channels x (TD x TH x TW) pixels.
-//   rows (and planes) of the tile are strided by the dilation D ("polyphase" in y/z), so
-//   the LDS halo in y/z is K-1 rows instead of (K-1)*D; columns are contiguous with a
+// Workgroup = 256 threads = 4 waves (one per SIMD); tile = MT output channels x (TD x TH x TW)
+//   pixels.  Rows (and planes) of the tile are strided by the dilation D ("polyphase" in y/z),
+//   so the LDS halo in y/z is K-1 rows instead of (K-1)*D; columns are contiguous with a
 //   (K-1)*D halo so every global row segment is a coalesced read.
-// LDS holds one channel chunk of the input tile plus the pre-packed weight chunk
-// (host packs weights in the exact lane order of the A fragment, so the A read is
-//  lds[step][mf][lane] and the B read is lds[ch][z][y][x] -- all offsets are immediates).
+// Pipeline: the K loop is cut into stages = (a chunk of 4*KG input channels) x (RPS tap rows).
+//   Both operands of stage s+1 are fetched by the LDS-DMA path (global_load_lds, no VGPRs)
+//   into the second LDS buffer while the MFMAs of stage s run; one barrier per stage.
+//   Weights are pre-packed on the host in A-fragment lane order, so the A read is
+//   lds[step][mf][lane], the B read is lds[ch][z][y][x]; all ds_read offsets are immediates.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,30 +29,31 @@ namespace tpz {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
-    const float* in;          // [Cin][Din][Hin][Win]
+    const float* in;          // [Cin1][D1][H1][W1] (strided)
     const float* in2;         // optional 2nd source: channels [Cin1, Cin) come from here (fused concat)
-    const float* wpk;         // packed weights (see pack_weights)
+    const float* wpk;         // packed weights (runtime.hip pack_weights)
     const float* bias;        // [Cout] or nullptr
-    float* out;               // [Cout][Dout][Hout][Wout] (or nullptr when head is fused)
+    float* out;               // [Cout][Dout][Hout][Wout] (nullptr when the head is fused)
     const float* res;         // residual [Cout][Dres][Hres][Wres] or nullptr
     const float* post_scale;  // [Cout] affine applied after the residual add (eval BN), or nullptr
     const float* post_shift;
     const float* head_w;      // fused 1x1 head: [Cout] weights, or nullptr
     float* head_out;          // [Dout][Hout][Wout]
-    float head_b;
+    const float* zeros;       // >= 16 bytes of zeros in global memory (source of padded / OOB elements)
     const float* nrm;         // device float[4] {in_scale, in_shift, out_scale, out_shift} or nullptr
-    int norm_src;             // bit0: x' = x*in_scale+in_shift on in-bounds pixels of `in`; bit1: same for `in2`
+    float head_b;
+    int norm_src;             // (direct kernel only) bit0: x' = x*in_scale+in_shift on in-bounds pixels of `in`
     int norm_out;             // y' = y*out_scale+out_shift applied last
     int Cin, Cin1;            // Cin1 = channels taken from `in` (== Cin when no concat)
-    int Din, Hin, Win;        // geometry of `in2`/logical input (after nearest upsample of `in`)
-    int D1, H1, W1;           // geometry of `in` when it is nearest-upsampled to (Din,Hin,Win); else == Din..
-    long long cs1, ps1; int pitch1;   // channel / plane / row strides (floats) of `in`  (views into larger images)
+    int Din, Hin, Win;        // logical input geometry (== geometry of in2; `in` is nearest-upsampled to it)
+    int D1, H1, W1;           // geometry of `in`
+    long long cs1, ps1; int pitch1;   // channel / plane / row strides (floats) of `in`
     long long cs2, ps2; int pitch2;   // ... of `in2`
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int Cout, Dout, Hout, Wout;
     int pad;                  // zero padding on every side
     int Dres, Hres, Wres, res_crop;
-    int n_chunks;
+    int n_chunks;             // channel chunks of NCH channels
     float slope;              // activation: v > 0 ? v : v*slope   (1.0 = identity, 0.0 = ReLU)
     int tiles_x, tiles_y, tiles_z;
 };
@@ -62,9 +66,9 @@ __device__ __forceinline__ int nearest_src(int dst, int in_sz, int out_sz) {
     return s < in_sz - 1 ? s : in_sz - 1;
 }
 
-template <int K_, int D_, int MT_, int TD_, int TH_, int TW_, int KG_, bool CIN1_, int DIMS_>
+template <int K_, int D_, int MT_, int TD_, int TH_, int TW_, int KG_, int RPS_, bool CIN1_, int DIMS_>
 struct ConvCfg {
-    static constexpr int K = K_, D = D_, MT = MT_, TD = TD_, TH = TH_, TW = TW_, KG = KG_, DIMS = DIMS_;
+    static constexpr int K = K_, D = D_, MT = MT_, TD = TD_, TH = TH_, TW = TW_, KG = KG_, RPS = RPS_, DIMS = DIMS_;
     static constexpr bool CIN1 = CIN1_;
     static constexpr int KZ = (DIMS == 3) ? K : 1;
     static constexpr int MW = MT / 16;
@@ -73,212 +77,268 @@ struct ConvCfg {
     static constexpr int NFC = TW / 16;             // N fragments per row
     static constexpr int NW = RPW * NFC;
     static constexpr int KP = CIN1 ? ((K + 3) / 4 * 4) : K;   // kx taps padded to a k-group
+    static constexpr int KXG = CIN1 ? KP / 4 : K;             // MFMA k-steps per tap row
     static constexpr int ITD = TD + KZ - 1;
     static constexpr int ITH = TH + K - 1;
     static constexpr int ITW = TW + (KP - 1) * D;
     static constexpr int RS = ITW;
     static constexpr int PS = ITH * RS;             // plane stride
-    static constexpr int CS_RAW = ITD * PS;
+    static constexpr int TILE_ELEMS = ITD * PS;
     // channel stride == 16 (mod 32): the two 16-lane halves of a ds_read_b32 group hit disjoint banks
-    static constexpr int CS = CIN1 ? CS_RAW : (((CS_RAW - 16 + 31) / 32) * 32 + 16);
+    static constexpr int CS = CIN1 ? TILE_ELEMS : (((TILE_ELEMS - 16 + 31) / 32) * 32 + 16);
     static constexpr int NCH = CIN1 ? 1 : 4 * KG;
-    static constexpr int IN_FLOATS = ((NCH * CS + 3) / 4) * 4;
-    static constexpr int NSTEP = CIN1 ? KZ * K * (KP / 4) : KG * KZ * K * K;
-    static constexpr int W_FLOATS = NSTEP * MW * 64;
-    static constexpr int LDS_BYTES = (IN_FLOATS + W_FLOATS) * 4;
+    static constexpr int IN_BUF = ((NCH * CS + 255) / 256) * 256;     // floats per input buffer (DMA granule 256)
+    static constexpr int NROWS = KZ * K;            // tap rows (kz, ky)
+    static constexpr int SPG = NROWS / RPS;         // stages per channel chunk
+    static constexpr int STEPS = (CIN1 ? 1 : KG) * RPS * KXG;         // MFMA k-steps per stage
+    static constexpr int W_STAGE = STEPS * MW * 64; // floats per weight stage
+    static constexpr int W_CHUNK = SPG * W_STAGE;   // floats per (co-group, chunk)
+    static constexpr int LDS_BYTES = (2 * IN_BUF + 2 * W_STAGE) * 4;
     // a wave's RPW tile rows either sit inside one z-plane, or cover whole z-planes
     static constexpr bool IN_PLANE = (TH % RPW == 0);
     static_assert(IN_PLANE || (RPW % TH == 0), "wave rows must align with z-planes");
     static constexpr int row_off(int row, int kz, int ky) {
         return IN_PLANE ? kz * PS + (row + ky) * RS : (row / TH + kz) * PS + (row % TH + ky) * RS;
     }
+    static_assert(NROWS % RPS == 0, "stages must tile the tap rows");
+    static_assert(RPS == 1 || RPS % K == 0, "a stage is one tap row or whole kz planes");
+    static_assert(SPG == 1 || KG == 1 || CIN1, "row-split stages need KG == 1");
     static_assert(ROWS % 4 == 0, "tile rows must split over 4 waves");
     static_assert(TW % 16 == 0 && MT % 16 == 0, "MFMA 16x16 fragments");
-    static_assert(IN_FLOATS * 4 < 65536 && W_FLOATS * 4 <= 65536, "ds_read immediate offsets are 16 bit");
+    static_assert(IN_BUF * 4 < 65536 && W_STAGE * 4 < 65536, "ds_read immediate offsets are 16 bit");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
 };
 
-template <class C>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ABL: timing-ablation switches used by tools/conv_ablate.hip only (production kernels use ABL = 0):
+//   1 no wave priority   2 skip the per-stage DMA issue   4 skip the per-stage barrier
+//   8 fragment loads only for the first step of a stage (operands reused)   16 setprio on even slots instead
+template <class C, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
-    constexpr int K = C::K, D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC, KZ = C::KZ;
+    constexpr int K = C::K, D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lds_in = lds;
-    float* lds_w = lds + C::IN_FLOATS;
+    float* lds_in = lds;                       // 2 x IN_BUF
+    float* lds_w = lds + 2 * C::IN_BUF;        // 2 x W_STAGE
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
 
+    // Two workgroups share a CU (two waves per SIMD, one from each).  Identical code makes them run in
+    // lockstep -- both in their DMA-issue / barrier phases at once, leaving the matrix pipe idle ~25 %.
+    // A static priority derived from the hardware wave slot (HW_REG_HW_ID.WAVE_ID, bit 0) breaks the
+    // symmetry: the odd slot's MFMAs always win arbitration, the even slot's fill every gap.
+    {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // WAVE_ID[3:0]
+        if constexpr (!(ABL & 1)) { if (hw_id & 1u) __builtin_amdgcn_s_setprio(2); }
+    }
+
     // ---- tile coordinates. y (and z) tiles are polyphase: row i of the tile is y0 + i*D.
-    const int bx = blockIdx.x;
-    int by = blockIdx.y;
-    const int tyz = by;                       // by enumerates (z tile, y tile) x phases
-    const int ty = tyz % a.tiles_y;
-    const int tz = tyz / a.tiles_y;
-    const int yb = ty / D, yph = ty % D;
-    const int y0 = yb * (C::TH * D) + yph;
-    int z0 = 0;
-    if (C::DIMS == 3) { const int zb = tz / D, zph = tz % D; z0 = zb * (C::TD * D) + zph; }
-    const int x0 = bx * C::TW;
+    const int ty = blockIdx.y % a.tiles_y;
+    const int tz = blockIdx.y / a.tiles_y;
+    const int y0 = (ty / D) * (C::TH * D) + (ty % D);
+    const int z0 = (C::DIMS == 3) ? (tz / D) * (C::TD * D) + (tz % D) : 0;
+    const int x0 = blockIdx.x * C::TW;
     const int ybase = y0 - a.pad, xbase = x0 - a.pad, zbase = (C::DIMS == 3) ? z0 - a.pad : 0;
 
-    // per-lane LDS read bases (floats)
-    const float* bl = lds_in + (C::CIN1 ? (l4 * D + l15) : (l4 * C::CS + l15));
-    const float* al = lds_w + lane;
-
+    // per-lane LDS read offsets (floats)
+    const int b_lane = (C::CIN1 ? (l4 * D + l15) : (l4 * C::CS + l15)) +
+                       (C::IN_PLANE ? ((wave * C::RPW) / C::TH) * C::PS + ((wave * C::RPW) % C::TH) * C::RS
+                                    : wave * (C::RPW / C::TH) * C::PS);
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win) || (a.D1 != a.Din);
-    float in_scale = 1.f, in_shift = 0.f, out_scale = 1.f, out_shift = 0.f;
-    if (a.nrm) { in_scale = a.nrm[0]; in_shift = a.nrm[1]; out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
-    const bool norm1 = (a.norm_src & 1) != 0, norm2 = (a.norm_src & 2) != 0;
+    float out_scale = 1.f, out_shift = 0.f;
+    if (a.nrm && a.norm_out) { out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
+
+    // ---- LDS-DMA issue helpers ------------------------------------------------------------------
+    // Input chunk -> lds_in buffer: element e = i*256 + tid of the padded [NCH][CS] LDS image comes from
+    // (channel c, z, y, x).  The per-thread source offsets (relative to the chunk's first channel) do not
+    // depend on the chunk, so they are computed ONCE per source tensor and kept in registers: the
+    // per-stage issue is one 64-bit add + one global_load_lds per element.  off < 0: padding or outside
+    // the image -> the element is fetched from the global zero word.
+    constexpr int NI = C::IN_BUF / 256;
+    int in_off[NI];
+    auto compute_offsets = [&](bool second) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = i * 256 + tid;
+            const int c = e / C::CS;
+            const int rem = e - c * C::CS;
+            const int zz = rem / C::PS;
+            const int rem2 = rem - zz * C::PS;
+            const int r = rem2 / C::RS;
+            const int x = rem2 - r * C::RS;
+            const int gy = ybase + r * D, gx = xbase + x;
+            const int gz = (C::DIMS == 3) ? zbase + zz * D : 0;
+            int off = -1;
+            if (rem < C::TILE_ELEMS && c < C::NCH && (unsigned)gy < (unsigned)a.Hin &&
+                (unsigned)gx < (unsigned)a.Win && (unsigned)gz < (unsigned)a.Din) {
+                if (!second) {
+                    int sy = gy, sx = gx, sz = gz;
+                    if (ups) {
+                        sy = nearest_src(gy, a.H1, a.Hin);
+                        sx = nearest_src(gx, a.W1, a.Win);
+                        if (C::DIMS == 3) sz = nearest_src(gz, a.D1, a.Din);
+                    }
+                    off = (int)((long long)c * a.cs1 + (long long)sz * a.ps1 + (long long)sy * a.pitch1 + sx);
+                } else {
+                    off = (int)((long long)c * a.cs2 + (long long)gz * a.ps2 + (long long)gy * a.pitch2 + gx);
+                }
+            }
+            in_off[i] = off;
+        }
+    };
+    // chunks [0, chunks1) read `in`, the rest read `in2` (the host guarantees Cin1 % NCH == 0 with a concat)
+    const int chunks1 = (a.in2 != nullptr) ? a.Cin1 / C::NCH : a.n_chunks;
+    auto issue_input = [&](int ch, int buf) {
+        float* dst = lds_in + buf * C::IN_BUF + wave * 64;
+        const bool second = ch >= chunks1;
+        const float* base = second ? a.in2 + (long long)(ch - chunks1) * C::NCH * a.cs2
+                                   : a.in + (long long)ch * C::NCH * a.cs1;
+        const int c_left = a.Cin - ch * C::NCH;      // channels of this chunk that exist (>= NCH except in the last)
+        if (c_left >= C::NCH) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float* src = in_off[i] >= 0 ? base + in_off[i] : a.zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + i * 256), 4, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = (i * 256 + tid) / C::CS;
+                const float* src = (in_off[i] >= 0 && c < c_left) ? base + in_off[i] : a.zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + i * 256), 4, 0, 0);
+            }
+        }
+    };
+    // weight stage `st` (global stage index within the co-group) -> lds_w buffer `buf`
+    auto issue_weights = [&](const float* wcog, int st, int buf) {
+        const float* src = wcog + (size_t)st * C::W_STAGE + tid * 4;
+        float* dst = lds_w + buf * C::W_STAGE + wave * 256;
+        constexpr int N4 = C::W_STAGE / 4;
+#pragma unroll
+        for (int i = 0; i < (N4 + 255) / 256; ++i) {
+            if (i * 256 + tid < N4)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
+        }
+    };
 
     float hsum[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
 
-  for (int cg = 0; cg < a.cog_inner; ++cg) {
-    const int cog = blockIdx.z * a.cog_inner + cg;
-    f32x4 acc[MW][NW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n_stages = a.n_chunks * C::SPG;
 
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
-        __syncthreads();
-        // ---- stage the input chunk: NCH channels x ITD x ITH x ITW, zero outside the image
-        constexpr int TILE_ELEMS = C::ITD * C::ITH * C::ITW;
-        constexpr int IN_ELEMS = C::NCH * TILE_ELEMS;
-#pragma unroll 4
-        for (int e = tid; e < IN_ELEMS; e += 256) {
-            const int c = e / TILE_ELEMS;
-            const int rem = e - c * TILE_ELEMS;
-            const int zz = rem / (C::ITH * C::ITW);
-            const int rem2 = rem - zz * (C::ITH * C::ITW);
-            const int r = rem2 / C::ITW;
-            const int x = rem2 - r * C::ITW;
-            const int ci = ch * C::NCH + c;
-            const int gy = ybase + r * D, gx = xbase + x;
-            const int gz = (C::DIMS == 3) ? zbase + zz * D : 0;
-            float v = 0.f;
-            if (ci < a.Cin && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win &&
-                (unsigned)gz < (unsigned)a.Din) {
-                if (ci < a.Cin1) {
-                    if (ups) {
-                        const int sy = nearest_src(gy, a.H1, a.Hin), sx = nearest_src(gx, a.W1, a.Win);
-                        const int sz = (C::DIMS == 3) ? nearest_src(gz, a.D1, a.Din) : 0;
-                        v = a.in[(long long)ci * a.cs1 + (long long)sz * a.ps1 + (long long)sy * a.pitch1 + sx];
-                    } else {
-                        v = a.in[(long long)ci * a.cs1 + (long long)gz * a.ps1 + (long long)gy * a.pitch1 + gx];
-                    }
-                    if (norm1) v = v * in_scale + in_shift;
+    for (int cg = 0; cg < a.cog_inner; ++cg) {
+        const int cog = blockIdx.z * a.cog_inner + cg;
+        const float* wcog = a.wpk + (size_t)cog * a.n_chunks * C::W_CHUNK;
+        f32x4 acc[MW][NW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        __syncthreads();                       // previous co-group done with the LDS buffers
+        compute_offsets(chunks1 == 0);
+        issue_input(0, 0);
+        issue_weights(wcog, 0, 0);
+        __syncthreads();                       // (vmcnt(0) + barrier)
+
+        for (int s = 0; s < n_stages; ++s) {
+            const int ch = s / C::SPG;         // SPG is a compile-time constant
+            const int j = s - ch * C::SPG;
+            // ---- prefetch stage s+1 by DMA while this stage computes
+            if constexpr (!(ABL & 2)) {
+                if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1);
+                if (j == 0 && ch + 1 < a.n_chunks) {
+                    if (ch + 1 == chunks1) compute_offsets(true);    // switching to the concatenated source
+                    issue_input(ch + 1, (ch + 1) & 1);
+                }
+            }
+
+            // ---- MFMAs of stage s
+            const int row0 = j * C::RPS;       // first tap row of the stage
+            const float* bl = lds_in + (ch & 1) * C::IN_BUF + b_lane +
+                              (C::RPS == 1 ? (row0 / K) * C::PS + (row0 % K) * C::RS : (row0 / K) * C::PS);
+            const float* al = lds_w + (s & 1) * C::W_STAGE + lane;
+            // fragment loads of step t+1 are issued ahead of the MFMAs of step t (register double buffer)
+            float av[2][MW], bv[2][NW];
+            auto load_frags = [&](int step, float (&a_)[MW], float (&b_)[NW]) {
+                const int kx = step % C::KXG;
+                const int r = (step / C::KXG) % C::RPS;
+                const int kg = step / (C::KXG * C::RPS);
+                const int rz = r / K, ry = r % K;                   // stage-relative (kz, ky)
+#pragma unroll
+                for (int m = 0; m < MW; ++m) a_[m] = al[(step * MW + m) * 64];
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    const int row = n / NFC, cc = n % NFC;
+                    const int off = C::row_off(row, rz, ry) + cc * 16 +
+                                    (C::CIN1 ? kx * 4 * D : kg * 4 * C::CS + kx * D);
+                    b_[n] = bl[off];
+                }
+            };
+            load_frags(0, av[0], bv[0]);
+#pragma unroll
+            for (int step = 0; step < C::STEPS; ++step) {
+                if constexpr (!(ABL & 8)) {
+                    if (step + 1 < C::STEPS) load_frags(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
                 } else {
-                    v = a.in2[(long long)(ci - a.Cin1) * a.cs2 + (long long)gz * a.ps2 + (long long)gy * a.pitch2 + gx];
-                    if (norm2) v = v * in_scale + in_shift;
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) av[(step + 1) & 1][m] = av[step & 1][m];
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) bv[(step + 1) & 1][n] = bv[step & 1][n];
                 }
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int n = 0; n < NW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m], bv[step & 1][n], acc[m][n],
+                                                                         0, 0, 0);
             }
-            lds_in[c * C::CS + zz * C::PS + r * C::RS + x] = v;
+            if constexpr (!(ABL & 4)) __syncthreads();   // stage s+1 landed (vmcnt(0)); stage s buffers free
         }
-        // ---- stage the weight chunk (already in fragment order)
-        {
-            const float4* wsrc =
-                reinterpret_cast<const float4*>(a.wpk + ((size_t)cog * a.n_chunks + ch) * C::W_FLOATS);
-            float4* wdst = reinterpret_cast<float4*>(lds_w);
-#pragma unroll 4
-            for (int e = tid; e < C::W_FLOATS / 4; e += 256) wdst[e] = wsrc[e];
-        }
-        __syncthreads();
 
-        // ---- MFMA over the chunk
-        const float* blw = bl + (C::IN_PLANE ? ((wave * C::RPW) / C::TH) * C::PS + ((wave * C::RPW) % C::TH) * C::RS
-                                             : wave * (C::RPW / C::TH) * C::PS);
-        if constexpr (C::CIN1) {
+        // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store
+        const size_t plane_out = (size_t)a.Hout * a.Wout;
+        const size_t vol_out = plane_out * a.Dout;
+        const size_t plane_res = (size_t)a.Hres * a.Wres;
+        const size_t vol_res = plane_res * a.Dres;
 #pragma unroll
-            for (int kz = 0; kz < KZ; ++kz)
+        for (int n = 0; n < NW; ++n) {
+            const int trow = wave * C::RPW + n / NFC;             // tile row, z-major
+            const int ti_z = trow / C::TH, ti_y = trow % C::TH;
+            const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
+            const int ox = x0 + (n % NFC) * 16 + l15;
+            const bool inb = (oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout);
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky)
+            for (int m = 0; m < MW; ++m) {
 #pragma unroll
-                for (int kg = 0; kg < C::KP / 4; ++kg) {
-                    const int step = (kz * K + ky) * (C::KP / 4) + kg;
-                    float av[MW], bv[NW];
-#pragma unroll
-                    for (int m = 0; m < MW; ++m) av[m] = al[(step * MW + m) * 64];
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) {
-                        const int row = n / NFC, cc = n % NFC;   // row within the wave
-                        bv[n] = blw[C::row_off(row, kz, ky) + cc * 16 + kg * 4 * D];
-                    }
-#pragma unroll
-                    for (int m = 0; m < MW; ++m)
-#pragma unroll
-                        for (int n = 0; n < NW; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int kg = 0; kg < C::KG; ++kg)
-#pragma unroll
-            for (int kz = 0; kz < KZ; ++kz)
-#pragma unroll
-                for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < K; ++kx) {
-                        const int step = ((kg * KZ + kz) * K + ky) * K + kx;
-                        float av[MW], bv[NW];
-#pragma unroll
-                        for (int m = 0; m < MW; ++m) av[m] = al[(step * MW + m) * 64];
-#pragma unroll
-                        for (int n = 0; n < NW; ++n) {
-                            const int row = n / NFC, cc = n % NFC;
-                            bv[n] = blw[kg * 4 * C::CS + C::row_off(row, kz, ky) + cc * 16 + kx * D];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = cog * C::MT + m * 16 + l4 * 4 + r;
+                    if (co < a.Cout && inb) {
+                        float v = acc[m][n][r];
+                        if (a.bias) v += a.bias[co];
+                        if (a.res) {
+                            const int c = a.res_crop;
+                            v += a.res[(size_t)co * vol_res + (size_t)(C::DIMS == 3 ? oz + c : 0) * plane_res +
+                                       (size_t)(oy + c) * a.Wres + (ox + c)];
                         }
-#pragma unroll
-                        for (int m = 0; m < MW; ++m)
-#pragma unroll
-                            for (int n = 0; n < NW; ++n)
-                                acc[m][n] =
-                                    __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-                    }
-        }
-    }
-
-    // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store
-    const size_t plane_out = (size_t)a.Hout * a.Wout;
-    const size_t vol_out = plane_out * a.Dout;
-    const size_t plane_res = (size_t)a.Hres * a.Wres;
-    const size_t vol_res = plane_res * a.Dres;
-#pragma unroll
-    for (int n = 0; n < NW; ++n) {
-        const int trow = wave * C::RPW + n / NFC;             // tile row, z-major
-        const int ti_z = trow / C::TH, ti_y = trow % C::TH;
-        const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
-        const int ox = x0 + (n % NFC) * 16 + l15;
-        const bool inb = (oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout);
-#pragma unroll
-        for (int m = 0; m < MW; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = cog * C::MT + m * 16 + l4 * 4 + r;
-                if (co < a.Cout && inb) {
-                    float v = acc[m][n][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.res) {
-                        const int c = a.res_crop;
-                        v += a.res[(size_t)co * vol_res + (size_t)(C::DIMS == 3 ? oz + c : 0) * plane_res +
-                                   (size_t)(oy + c) * a.Wres + (ox + c)];
-                    }
-                    if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
-                    v = v > 0.f ? v : v * a.slope;
-                    if (a.head_w) {
-                        hsum[n] += v * a.head_w[co];
-                    } else {
-                        if (a.norm_out) v = v * out_scale + out_shift;
-                        a.out[(size_t)co * vol_out + (size_t)oz * plane_out + (size_t)oy * a.Wout + ox] = v;
+                        if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
+                        v = v > 0.f ? v : v * a.slope;
+                        if (a.head_w) {
+                            hsum[n] += v * a.head_w[co];
+                        } else {
+                            if (a.norm_out) v = v * out_scale + out_shift;
+                            a.out[(size_t)co * vol_out + (size_t)oz * plane_out + (size_t)oy * a.Wout + ox] = v;
+                        }
                     }
                 }
             }
         }
-    }
-  }  // cog loop
+    }  // co-group loop
 
     if (a.head_w) {
         // fused 1x1 head: reduce over the four 16-lane groups (they hold different co of the same pixel)

@@ -8,7 +8,7 @@ namespace tpz {
 
 struct ConvKernelInfo {
     int dims, K, D, MT, cin1;
-    int TD, TH, TW, KG, KP, NCH, NSTEP, W_FLOATS, lds_bytes;
+    int TD, TH, TW, KG, RPS, KP, KXG, NCH, SPG, STEPS, W_STAGE, W_CHUNK, lds_bytes;
     hipError_t (*launch)(const ConvArgs&, dim3 grid, hipStream_t);
 };
 
@@ -33,8 +33,9 @@ struct ConvRegistrar {
     ConvRegistrar() {
         ConvKernelInfo i;
         i.dims = C::DIMS; i.K = C::K; i.D = C::D; i.MT = C::MT; i.cin1 = C::CIN1 ? 1 : 0;
-        i.TD = C::TD; i.TH = C::TH; i.TW = C::TW; i.KG = C::KG; i.KP = C::KP; i.NCH = C::NCH;
-        i.NSTEP = C::NSTEP; i.W_FLOATS = C::W_FLOATS; i.lds_bytes = C::LDS_BYTES;
+        i.TD = C::TD; i.TH = C::TH; i.TW = C::TW; i.KG = C::KG; i.RPS = C::RPS; i.KP = C::KP; i.KXG = C::KXG;
+        i.NCH = C::NCH; i.SPG = C::SPG; i.STEPS = C::STEPS; i.W_STAGE = C::W_STAGE; i.W_CHUNK = C::W_CHUNK;
+        i.lds_bytes = C::LDS_BYTES;
         i.launch = &launch_conv_cfg<C>;
         register_conv(i);
     }
@@ -43,9 +44,9 @@ struct ConvRegistrar {
 #define TPZ_CAT2(a, b) a##b
 #define TPZ_CAT(a, b) TPZ_CAT2(a, b)
 // 2-D kernels: DIMS=2, TD=1
-#define TPZ_CONV2D(K, D, MT, TH, TW, KG, CIN1) \
-    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, 1, TH, TW, KG, CIN1, 2>> TPZ_CAT(tpz_reg_, __COUNTER__);
-#define TPZ_CONV3D(K, D, MT, TD, TH, TW, KG, CIN1) \
-    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, TD, TH, TW, KG, CIN1, 3>> TPZ_CAT(tpz_reg_, __COUNTER__);
+#define TPZ_CONV2D(K, D, MT, TH, TW, KG, RPS, CIN1) \
+    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, 1, TH, TW, KG, RPS, CIN1, 2>> TPZ_CAT(tpz_reg_, __COUNTER__);
+#define TPZ_CONV3D(K, D, MT, TD, TH, TW, KG, RPS, CIN1) \
+    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, TD, TH, TW, KG, RPS, CIN1, 3>> TPZ_CAT(tpz_reg_, __COUNTER__);
 
 }  // namespace tpz

@@ -191,6 +191,31 @@ hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float 
     return hipGetLastError();
 }
 
+// y[z][y][x] (dense) = x_view[z][y][x]*p[0] + p[1] with p on the device: the (x - mu)/std step of
+// Denoise._denoise (denoise.py:284) applied to a (strided) patch view before the network reads it.
+__global__ __launch_bounds__(256) void affine_dev_kernel(const float* __restrict__ x, int D, int H, int W,
+                                                         long long ps, int pitch, const float* __restrict__ p,
+                                                         float* __restrict__ y) {
+    const size_t n = (size_t)D * H * W;
+    const float sc = p[0], sh = p[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int xx = (int)(i % W);
+        const size_t t = i / W;
+        const int yy = (int)(t % H);
+        const int zz = (int)(t / H);
+        y[i] = x[(long long)zz * ps + (long long)yy * pitch + xx] * sc + sh;
+    }
+}
+
+hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, int pitch, const float* d_p, float* y,
+                             hipStream_t s) {
+    const size_t n = (size_t)D * H * W;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(affine_dev_kernel, dim3(blocks), dim3(256), 0, s, x, D, H, W, ps, pitch, d_p, y);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // copy a box: dst[dz0+z][dy0+y][dx0+x] = src[sz0+z][sy0+y][sx0+x]   (stitching, denoise.py:322,365-369)
 // ------------------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ struct tpz_ctx {
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
     unsigned int* d_counters = nullptr;
+    float* d_zeros = nullptr;     // 256 B of zeros: DMA source of padded / out-of-image elements
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -229,45 +230,42 @@ static const ConvKernelInfo* choose_kernel(const tpz_layer& L, bool* cin1_out) {
     return best;
 }
 
-// weights [cout][cin][kz][ky][kx] -> per (co-group, channel chunk) blocks in A-fragment lane order:
+// weights [cout][cin][kz][ky][kx] -> per (co-group, channel chunk, stage) blocks in A-fragment lane order:
 //   block[step][mf][k(0..3)][i(0..15)]  with lane = k*16 + i   (conv_mfma.h)
+//   generic: step = (kg*RPS + r)*K + kx, tap row = stage*RPS + r = kz*K + ky, ci = chunk*NCH + kg*4 + k
+//   CIN1:    step = r*KXG + kxg,         kx = kxg*4 + k (zero beyond K), ci = 0
 static void pack_weights(const ConvKernelInfo& ki, const float* w, int cout, int cin, int n_cog, int n_chunks,
                          std::vector<float>& out) {
     const int K = ki.K, KZ = ki.dims == 3 ? K : 1, MW = ki.MT / 16;
-    out.assign((size_t)n_cog * n_chunks * ki.W_FLOATS, 0.f);
+    out.assign((size_t)n_cog * n_chunks * ki.W_CHUNK, 0.f);
     const size_t taps = (size_t)KZ * K * K;
     for (int cog = 0; cog < n_cog; ++cog)
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            float* blk = out.data() + ((size_t)cog * n_chunks + ch) * ki.W_FLOATS;
-            for (int step = 0; step < ki.NSTEP; ++step) {
-                for (int mf = 0; mf < MW; ++mf)
-                    for (int k = 0; k < 4; ++k)
-                        for (int i = 0; i < 16; ++i) {
-                            const int co = cog * ki.MT + mf * 16 + i;
-                            int ci, kz, ky, kx;
-                            if (ki.cin1) {
-                                const int ng = ki.KP / 4;
-                                const int kg = step % ng;
-                                const int t = step / ng;
-                                ky = t % K;
-                                kz = t / K;
-                                kx = kg * 4 + k;
-                                ci = 0;
-                            } else {
-                                int t = step;
-                                kx = t % K; t /= K;
-                                ky = t % K; t /= K;
-                                kz = t % KZ; t /= KZ;
-                                const int kg = t;
-                                ci = ch * ki.NCH + kg * 4 + k;
+        for (int ch = 0; ch < n_chunks; ++ch)
+            for (int j = 0; j < ki.SPG; ++j) {
+                float* blk = out.data() + ((size_t)cog * n_chunks + ch) * ki.W_CHUNK + (size_t)j * ki.W_STAGE;
+                for (int step = 0; step < ki.STEPS; ++step)
+                    for (int mf = 0; mf < MW; ++mf)
+                        for (int k = 0; k < 4; ++k)
+                            for (int i = 0; i < 16; ++i) {
+                                const int co = cog * ki.MT + mf * 16 + i;
+                                int ci, kx, row;
+                                if (ki.cin1) {
+                                    row = j * ki.RPS + step / ki.KXG;
+                                    kx = (step % ki.KXG) * 4 + k;
+                                    ci = 0;
+                                } else {
+                                    const int kg = step / (ki.RPS * K);
+                                    row = j * ki.RPS + (step / K) % ki.RPS;
+                                    kx = step % K;
+                                    ci = ch * ki.NCH + kg * 4 + k;
+                                }
+                                const int kz = row / K, ky = row % K;
+                                float v = 0.f;
+                                if (co < cout && ci < cin && kx < K)
+                                    v = w[((size_t)co * cin + ci) * taps + ((size_t)kz * K + ky) * K + kx];
+                                blk[((size_t)step * MW + mf) * 64 + k * 16 + i] = v;
                             }
-                            float v = 0.f;
-                            if (co < cout && ci < cin && kx < K)
-                                v = w[((size_t)co * cin + ci) * taps + ((size_t)kz * K + ky) * K + kx];
-                            blk[((size_t)step * MW + mf) * 64 + k * 16 + i] = v;
-                        }
             }
-        }
 }
 
 static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const float* blob, size_t n_floats,
@@ -328,6 +326,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.head_w = rt.d_head_w;
     a.head_b = rt.head_b;
     a.nrm = d_nrm;
+    a.zeros = ctx->d_zeros;
     a.norm_src = d_nrm ? norm_src : 0;
     a.norm_out = d_nrm ? norm_out : 0;
     a.Cin = L.cin;
@@ -347,6 +346,8 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
     if (rt.ki) {
         const ConvKernelInfo& ki = *rt.ki;
+        if (s2 && (s1.C % ki.NCH) != 0)
+            return fail(ctx, "fused concat needs the first source's channels (%d) to be a multiple of %d", s1.C, ki.NCH);
         a.n_chunks = rt.n_chunks;
         a.cog_inner = rt.cog_inner;
         a.tiles_x = (dst.W + ki.TW - 1) / ki.TW;
@@ -404,8 +405,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
                 rc = fail(ctx, "layer %d: residual geometry mismatch", i);
                 break;
             }
-            int norm_src = 0;
-            if (d_nrm) norm_src = (L.src == 0 ? 1 : 0) | (L.src2 == 0 ? 2 : 0);
+            const int norm_src = 0;      // slot 0 arrives already normalised (denoise_region)
             rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, norm_src, (d_nrm && i == nl - 1) ? 1 : 0);
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
@@ -465,7 +465,8 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (hipMalloc((void**)&ctx->d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned int)) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_zeros, 256) != hipSuccess || hipMemset(ctx->d_zeros, 0, 256) != hipSuccess) {
         delete ctx;
         return fail(nullptr, "tpz_ctx_create: hipMalloc failed");
     }
@@ -481,6 +482,7 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipFree(ctx->d_part);
     (void)hipFree(ctx->d_nrm);
     (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_zeros);
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -556,6 +558,17 @@ int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int
     return 0;
 }
 
+int tpz_model_out_channels(tpz_model* m, int* C) {
+    if (!m || !C) return fail(nullptr, "tpz_model_out_channels: NULL argument");
+    const tpz_layer& L = m->layers.back().L;
+    if (L.op == TPZ_OP_CONV) { *C = L.head ? 1 : L.cout; return 0; }
+    // pooling keeps the channels of its source conv
+    for (int i = (int)m->layers.size() - 1; i >= 0; --i)
+        if (m->layers[i].L.op == TPZ_OP_CONV) { *C = m->layers[i].L.head ? 1 : m->layers[i].L.cout; return 0; }
+    *C = 1;
+    return 0;
+}
+
 int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out) {
     if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_model_forward: NULL argument");
     tpz_ctx* ctx = m->ctx;
@@ -563,27 +576,42 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
     int Do, Ho, Wo;
     tpz_model_out_shape(m, D, H, W, &Do, &Ho, &Wo);
     if (Do < 1 || Ho < 1 || Wo < 1) return fail(ctx, "input %dx%dx%d too small for this model", D, H, W);
+    int Co = 1;
+    tpz_model_out_channels(m, &Co);
     for (int b = 0; b < n; ++b) {
         std::vector<Slot> slots(m->n_slots);
         set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
-        if (run_program(m, slots, d_out + (size_t)b * Do * Ho * Wo, nullptr)) return 1;
+        if (run_program(m, slots, d_out + (size_t)b * Co * Do * Ho * Wo, nullptr)) return 1;
     }
     return 0;
 }
 
 // ---- denoising ---------------------------------------------------------------------------------
-static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int dims) {
+// Denoise._denoise on a (strided) region: mean / unbiased std -> normalise -> network -> un-normalise.
+// mode 1: plain; mode 2: the un-normalisation also applies the volume's std*y+mu with g = {mu, std}.
+static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int dims, int mode = 1,
+                          const float* d_g = nullptr) {
     tpz_ctx* ctx = m->ctx;
     float* nrm = next_nrm(ctx);
     prof_begin(ctx, 2, 0);
-    hipError_t e = launch_meanstd(view.p, view.D, view.H, view.W, view.ps, view.pitch, /*unbiased*/ 1, /*mode*/ 1,
-                                  nullptr, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
+    hipError_t e = launch_meanstd(view.p, view.D, view.H, view.W, view.ps, view.pitch, /*unbiased*/ 1, mode,
+                                  d_g, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
     prof_end(ctx);
     HIPCHK(ctx, e);
+    // (x - mu)/std once, into a dense buffer every reader of slot 0 (first conv, dec1 concat) DMA-loads
+    const size_t n = (size_t)view.D * view.H * view.W;
+    float* xn = (float*)pool_alloc(ctx, n * sizeof(float));
+    if (!xn) return fail(ctx, "out of device memory");
+    prof_begin(ctx, 2, 0);
+    e = launch_affine_dev(view.p, view.D, view.H, view.W, view.ps, view.pitch, nrm, xn, ctx->stream);
+    prof_end(ctx);
+    if (e != hipSuccess) { pool_release(ctx, xn); return fail(ctx, "affine_dev failed: %s", hipGetErrorString(e)); }
     std::vector<Slot> slots(m->n_slots);
-    slots[0] = view;
+    set_dense(slots[0], xn, 1, view.D, view.H, view.W);
     (void)dims;
-    return run_program(m, slots, d_out_dense, nrm);
+    const int rc = run_program(m, slots, d_out_dense, nrm);
+    pool_release(ctx, xn);
+    return rc;
 }
 
 int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out) {
@@ -653,12 +681,9 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
                 hipError_t e = launch_extract_tile3d(d_in, D, H, W, i - pad, j - pad, k - pad, d, g, tile, ctx->stream);
                 prof_end(ctx);
                 if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
-                float* nrm = next_nrm(ctx);
-                e = launch_meanstd(tile, d, d, d, (long long)d * d, d, 1, 2, g, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
-                if (e != hipSuccess) { rc = fail(ctx, "meanstd failed: %s", hipGetErrorString(e)); break; }
-                std::vector<Slot> slots(m->n_slots);
-                set_dense(slots[0], tile, 1, d, d, d);
-                rc = run_program(m, slots, tout, nrm);
+                Slot tv;
+                set_dense(tv, tile, 1, d, d, d);
+                rc = denoise_region(m, tv, tout, 3, 2, g);
                 if (rc) break;
                 const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
                 prof_begin(ctx, 2, 0);

@@ -191,7 +191,9 @@ class DeviceModel:
         Do, Ho, Wo = self.out_shape(D, H, W)
         if min(Do, Ho, Wo) < 1:
             raise ValueError(f'input {tuple(x.shape)} is too small for this model')
-        shape = (N, 1, Do, Ho, Wo) if nd == 3 else (N, 1, Ho, Wo)
+        co = C.c_int(1)
+        check(self.ctx.lib.tpz_model_out_channels(self.handle, C.byref(co)), self.ctx.handle)
+        shape = (N, co.value, Do, Ho, Wo) if nd == 3 else (N, co.value, Ho, Wo)
         y = torch.empty(shape, dtype=torch.float32, device=x.device)
         check(self.ctx.lib.tpz_model_forward(self.handle, _ptr(x), N, D, H, W, _ptr(y)), self.ctx.handle)
         return y
