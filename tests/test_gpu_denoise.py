@@ -77,3 +77,18 @@ def test_user_model_pickle(gpu_ctx):
     z = load_golden('denoise2d_unet_b11t5_nf16')
     d = Denoise(os.path.join(GOLDEN, 'user_model_unet_b11t5_nf16.sav'))
     assert _err(d.denoise(z['x'], 48, 20), z['p48_20']) <= ATOL
+
+
+def test_unet3d_nf48_tile_vs_oracle(gpu_ctx):
+    """the pretrained 3-D architecture (nf 48, base 7; blob missing upstream) with seeded weights on
+    one 64^3 tile through Denoise3D._denoise, and a 2x2x1 tile grid with 32/16 patches"""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)
+    d = Denoise3D(DenoiseNet('unet-3d', sd))
+    v = np.random.RandomState(2000).randn(64, 64, 64).astype(np.float32)
+    ref = oden.denoise3d(sd, v, -1, 0)
+    assert _err(d.denoise(v, -1, verbose=False), ref) <= ATOL
+    t = np.random.RandomState(2001).randn(30, 40, 50).astype(np.float32) * 2 + 3
+    ref = oden.denoise3d(sd, t, 32, 16)
+    assert _err(d.denoise(t, 32, 16, verbose=False), ref, 2.0) <= ATOL

@@ -131,3 +131,50 @@ def test_filter_2d_gaussian(gpu_ctx):
     x = torch.randn(90, 77)
     ref = F.conv2d(x[None, None], torch.from_numpy(f)[None, None], padding=f.shape[0] // 2)[0, 0]
     _close(rt.filter_2d(x, f), ref, atol=1e-5)
+
+
+CONV3D_CASES = [
+    # cin, cout, k, pad, D, H, W, slope
+    (1, 48, 7, 3, 20, 22, 40, 0.1),        # CIN1 3-D stem
+    (1, 8, 7, 3, 9, 17, 33, 0.1),
+    (48, 48, 3, 1, 12, 14, 36, 0.1),
+    (96, 96, 3, 1, 6, 9, 33, 0.1),
+    (64, 32, 3, 1, 10, 9, 20, 0.1),
+    (16, 16, 3, 1, 7, 6, 5, 0.1),
+    (32, 1, 3, 1, 9, 10, 11, 1.0),         # direct kernel
+]
+
+
+@pytest.mark.parametrize('case', CONV3D_CASES)
+def test_conv3d(gpu_ctx, case):
+    from topaz_amd import runtime as rt
+    cin, cout, k, pad, D, H, W, slope = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) / np.sqrt(cin * k ** 3)
+    b = torch.randn(cout, generator=g)
+    ref = _act(F.conv3d(x[None], w, b, padding=pad)[0], slope)
+    y = rt.conv(x, w.numpy(), b.numpy(), pad=pad, slope=slope)
+    _close(y, ref)
+
+
+@pytest.mark.parametrize('shape', [((96, 5, 6, 7), (11, 13, 15)), ((16, 3, 3, 3), (6, 6, 6))])
+def test_conv3d_fused_upsample_concat(gpu_ctx, shape):
+    from topaz_amd import runtime as rt
+    (c1, d1, h1, w1), (D, H, W) = shape
+    g = torch.Generator().manual_seed(6)
+    h = torch.randn(c1, d1, h1, w1, generator=g)
+    skip = torch.randn(c1 // 2, D, H, W, generator=g)
+    cin = c1 + skip.shape[0]
+    w = torch.randn(96, cin, 3, 3, 3, generator=g) / np.sqrt(cin * 27)
+    b = torch.randn(96, generator=g)
+    cat = torch.cat([F.interpolate(h[None], size=(D, H, W), mode='nearest'), skip[None]], 1)
+    ref = F.leaky_relu(F.conv3d(cat, w, b, padding=1), 0.1)[0]
+    y = rt.conv(h, w.numpy(), b.numpy(), pad=1, slope=0.1, x2=skip)
+    _close(y, ref)
+
+
+def test_maxpool3d(gpu_ctx):
+    from topaz_amd import runtime as rt
+    x = torch.randn(7, 9, 11, 13)
+    assert torch.equal(rt.maxpool2(x).cpu(), F.max_pool3d(x[None], 2)[0])

@@ -2,7 +2,7 @@
 #include "conv_registry.h"
 TPZ_CONV2D(1, 1, 64, 16, 32, 4, 1, false)
 TPZ_CONV2D(1, 1, 128, 8, 32, 4, 1, false)
-TPZ_CONV2D(7, 1, 32, 16, 64, 1, 7, true)
+TPZ_CONV2D(7, 1, 32, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 48, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 64, 16, 32, 1, 7, true)
 TPZ_CONV2D(11, 1, 48, 16, 32, 1, 11, true)

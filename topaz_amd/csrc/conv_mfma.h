@@ -93,7 +93,8 @@ struct ConvCfg {
     static constexpr int STEPS = (CIN1 ? 1 : KG) * RPS * KXG;         // MFMA k-steps per stage
     static constexpr int W_STAGE = STEPS * MW * 64; // floats per weight stage
     static constexpr int W_CHUNK = SPG * W_STAGE;   // floats per (co-group, chunk)
-    static constexpr int LDS_BYTES = (2 * IN_BUF + 2 * W_STAGE) * 4;
+    // LDS: 2 input buffers, 2 weight stages, and the per-element DMA source-offset table (IN_BUF words)
+    static constexpr int LDS_BYTES = (3 * IN_BUF + 2 * W_STAGE) * 4;
     // a wave's RPW tile rows either sit inside one z-plane, or cover whole z-planes
     static constexpr bool IN_PLANE = (TH % RPW == 0);
     static_assert(IN_PLANE || (RPW % TH == 0), "wave rows must align with z-planes");
@@ -112,6 +113,28 @@ struct ConvCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA (global_load_lds) in the SGPR-base + 32-bit VGPR-offset form.  Written as inline asm so that the
+// address stays one VGPR per element (hipcc otherwise materialises -- and spills -- 64-bit pointers, and
+// waits vmcnt(0) on every reload, serialising the DMA).  Data lands at lds_addr + lane*size.  M0 is
+// saved/restored inside the statement (cdna_hip_programming.md 5.7).  hipcc does not count these loads:
+// the pipeline waits with an explicit `s_waitcnt vmcnt(0)` before each stage barrier.
+__device__ __forceinline__ void glds_b32(unsigned voff, const void* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void glds_b128(unsigned voff, const void* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+
 // ABL: timing-ablation switches used by tools/conv_ablate.hip only (production kernels use ABL = 0):
 //   1 no wave priority   2 skip the per-stage DMA issue   4 skip the per-stage barrier
 //   8 fragment loads only for the first step of a stage (operands reused)   16 setprio on even slots instead
@@ -121,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_in = lds;                       // 2 x IN_BUF
     float* lds_w = lds + 2 * C::IN_BUF;        // 2 x W_STAGE
+    unsigned* lds_tab = reinterpret_cast<unsigned*>(lds + 2 * C::IN_BUF + 2 * C::W_STAGE);   // IN_BUF offsets
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -159,9 +183,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // per-stage issue is one 64-bit add + one global_load_lds per element.  off < 0: padding or outside
     // the image -> the element is fetched from the global zero word.
     constexpr int NI = C::IN_BUF / 256;
-    int in_off[NI];
+    constexpr unsigned OOB = 0xffffffffu;  // table entry of an element outside the image (zero-filled)
+    // Source byte offsets (relative to the chunk's first channel) of all IN_BUF elements.  They do not
+    // depend on the chunk, so they are computed once per source tensor into an LDS table (keeping them in
+    // VGPRs next to 128 accumulators made hipcc spill); each stage re-reads its NI entries.
     auto compute_offsets = [&](bool second) {
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < NI; ++i) {
             const int e = i * 256 + tid;
             const int c = e / C::CS;
@@ -172,56 +199,66 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int x = rem2 - r * C::RS;
             const int gy = ybase + r * D, gx = xbase + x;
             const int gz = (C::DIMS == 3) ? zbase + zz * D : 0;
-            int off = -1;
-            if (rem < C::TILE_ELEMS && c < C::NCH && (unsigned)gy < (unsigned)a.Hin &&
-                (unsigned)gx < (unsigned)a.Win && (unsigned)gz < (unsigned)a.Din) {
-                if (!second) {
-                    int sy = gy, sx = gx, sz = gz;
-                    if (ups) {
-                        sy = nearest_src(gy, a.H1, a.Hin);
-                        sx = nearest_src(gx, a.W1, a.Win);
-                        if (C::DIMS == 3) sz = nearest_src(gz, a.D1, a.Din);
+            unsigned off = 0;              // LDS padding elements are never read: they fetch the chunk's first word
+            if (rem < C::TILE_ELEMS && c < C::NCH) {
+                if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && (unsigned)gz < (unsigned)a.Din) {
+                    long long o;
+                    if (!second) {
+                        int sy = gy, sx = gx, sz = gz;
+                        if (ups) {
+                            sy = nearest_src(gy, a.H1, a.Hin);
+                            sx = nearest_src(gx, a.W1, a.Win);
+                            if (C::DIMS == 3) sz = nearest_src(gz, a.D1, a.Din);
+                        }
+                        o = (long long)c * a.cs1 + (long long)sz * a.ps1 + (long long)sy * a.pitch1 + sx;
+                    } else {
+                        o = (long long)c * a.cs2 + (long long)gz * a.ps2 + (long long)gy * a.pitch2 + gx;
                     }
-                    off = (int)((long long)c * a.cs1 + (long long)sz * a.ps1 + (long long)sy * a.pitch1 + sx);
+                    off = (unsigned)(o * 4);
                 } else {
-                    off = (int)((long long)c * a.cs2 + (long long)gz * a.ps2 + (long long)gy * a.pitch2 + gx);
+                    off = OOB;
                 }
             }
-            in_off[i] = off;
+            lds_tab[e] = off;              // read back by the same thread only
         }
     };
     // chunks [0, chunks1) read `in`, the rest read `in2` (the host guarantees Cin1 % NCH == 0 with a concat)
     const int chunks1 = (a.in2 != nullptr) ? a.Cin1 / C::NCH : a.n_chunks;
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;     // LDS byte address of the dynamic region
     auto issue_input = [&](int ch, int buf) {
-        float* dst = lds_in + buf * C::IN_BUF + wave * 64;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + wave * 64) * 4u);
         const bool second = ch >= chunks1;
-        const float* base = second ? a.in2 + (long long)(ch - chunks1) * C::NCH * a.cs2
-                                   : a.in + (long long)ch * C::NCH * a.cs1;
+        const void* base = uniform_ptr(second ? a.in2 + (long long)(ch - chunks1) * C::NCH * a.cs2
+                                              : a.in + (long long)ch * C::NCH * a.cs1);
+        const void* zbase = uniform_ptr(a.zeros);
         const int c_left = a.Cin - ch * C::NCH;      // channels of this chunk that exist (>= NCH except in the last)
-        if (c_left >= C::NCH) {
+        unsigned off[NI];
+        bool any_oob = false;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const float* src = in_off[i] >= 0 ? base + in_off[i] : a.zeros;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + i * 256), 4, 0, 0);
-            }
+        for (int i = 0; i < NI; ++i) {
+            off[i] = lds_tab[i * 256 + tid];
+            if (c_left < C::NCH && (i * 256 + tid) / C::CS >= c_left) off[i] = OOB;
+            any_oob |= (off[i] == OOB);
+        }
+        if (!__any(any_oob)) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) glds_b32(off[i], base, dst + i * 1024);
         } else {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int c = (i * 256 + tid) / C::CS;
-                const float* src = (in_off[i] >= 0 && c < c_left) ? base + in_off[i] : a.zeros;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + i * 256), 4, 0, 0);
+                if (off[i] != OOB) glds_b32(off[i], base, dst + i * 1024);
+                else glds_b32(0u, zbase, dst + i * 1024);
             }
         }
     };
     // weight stage `st` (global stage index within the co-group) -> lds_w buffer `buf`
     auto issue_weights = [&](const float* wcog, int st, int buf) {
-        const float* src = wcog + (size_t)st * C::W_STAGE + tid * 4;
-        float* dst = lds_w + buf * C::W_STAGE + wave * 256;
+        const void* base = uniform_ptr(wcog + (size_t)st * C::W_STAGE);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(2 * C::IN_BUF + buf * C::W_STAGE + wave * 256) * 4u);
         constexpr int N4 = C::W_STAGE / 4;
 #pragma unroll
         for (int i = 0; i < (N4 + 255) / 256; ++i) {
-            if (i * 256 + tid < N4)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
+            if (i * 256 + tid < N4) glds_b128((unsigned)(i * 256 + tid) * 16u, base, dst + i * 4096);
         }
     };
 
@@ -244,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         compute_offsets(chunks1 == 0);
         issue_input(0, 0);
         issue_weights(wcog, 0, 0);
-        __syncthreads();                       // (vmcnt(0) + barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 
         for (int s = 0; s < n_stages; ++s) {
             const int ch = s / C::SPG;         // SPG is a compile-time constant
@@ -298,7 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[step & 1][m], bv[step & 1][n], acc[m][n],
                                                                          0, 0, 0);
             }
-            if constexpr (!(ABL & 4)) __syncthreads();   // stage s+1 landed (vmcnt(0)); stage s buffers free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of stage s+1 has landed
+            if constexpr (!(ABL & 4)) __syncthreads();         // ... everyone's has; stage s buffers are free
         }
 
         // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store
