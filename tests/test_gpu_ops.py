@@ -41,6 +41,16 @@ CONV_CASES = [
     (1, 1, 31, 1, 15, 50, 60, 1.0),        # affine / gaussian filter
     (16, 16, 5, 16, 0, 90, 100, 0.25),     # conv127 last layer, PReLU slope
     (16, 24, 3, 1, 1, 20, 20, 0.1),        # cout not a multiple of 16
+    # widths that are multiples of 4: the 16-byte LDS-DMA mode (aligned tile origin, PADA = roundup4(pad))
+    (64, 64, 3, 2, 0, 67, 96, 0.0),
+    (64, 128, 5, 4, 0, 50, 64, 0.0),
+    (48, 48, 3, 1, 1, 45, 48, 0.1),
+    (97, 64, 5, 1, 2, 37, 44, 0.1),
+    (96, 96, 3, 1, 1, 8, 8, 0.1),          # image smaller than a tile
+    (1, 64, 7, 1, 35, 40, 52, 0.0),
+    (1, 48, 11, 1, 5, 50, 100, 0.1),
+    (32, 64, 1, 1, 0, 33, 40, 1.0),
+    (16, 16, 5, 16, 0, 90, 100, 0.25),
 ]
 
 
@@ -89,7 +99,8 @@ def test_conv2d_fused_head(gpu_ctx, cout):
     _close(y, ref)
 
 
-@pytest.mark.parametrize('shape', [((48, 23, 31), (47, 63)), ((96, 16, 16), (32, 32)), ((20, 9, 7), (19, 15))])
+@pytest.mark.parametrize('shape', [((48, 23, 31), (47, 63)), ((96, 16, 16), (32, 32)), ((20, 9, 7), (19, 15)),
+                                   ((48, 24, 30), (48, 60)), ((96, 190, 95), (381, 192))])
 def test_conv2d_fused_upsample_concat(gpu_ctx, shape):
     """F.interpolate(h, size, 'nearest') + torch.cat([h, skip]) folded into the conv's loader
     (denoising/models.py:140-171), including the odd sizes where src != dst//2 (SURVEY P9)."""
@@ -141,6 +152,8 @@ CONV3D_CASES = [
     (96, 96, 3, 1, 6, 9, 33, 0.1),
     (64, 32, 3, 1, 10, 9, 20, 0.1),
     (16, 16, 3, 1, 7, 6, 5, 0.1),
+    (48, 48, 3, 1, 9, 11, 40, 0.1),        # W % 4 == 0: 16-byte DMA mode
+    (1, 48, 7, 3, 12, 13, 36, 0.1),
     (32, 1, 3, 1, 9, 10, 11, 1.0),         # direct kernel
 ]
 

@@ -54,8 +54,9 @@ int bench(const char* name, int cin, int cout, int H) {
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP) LDS=%d B\n", name, cin, cout, Ho, tf, C::LDS_BYTES);
 #define RUN(ABL, label) { float ms = run<C, ABL>(a, grid, 2); printf("  %-44s %8.3f ms  %6.1f TF/s\n", label, ms, tf / (ms * 1e-3)); }
-    RUN(0, "baseline (prio odd slots)");
-    RUN(1, "no priority");
+    RUN(0, "baseline");
+    RUN(0, "baseline (again)");
+    RUN(16, "static priority on odd wave slots");
     RUN(2, "no per-stage DMA issue");
     RUN(4, "no per-stage barrier");
     RUN(8, "no LDS fragment reads after step 0");

@@ -3,9 +3,9 @@
 #include "conv_registry.h"
 //          K  D  MT  TD TH  TW KG RPS CIN1
 TPZ_CONV3D(3, 1, 16, 4, 4, 32, 1, 3, false)
-TPZ_CONV3D(3, 1, 32, 4, 4, 32, 1, 3, false)
-TPZ_CONV3D(3, 1, 48, 4, 4, 32, 1, 3, false)
-TPZ_CONV3D(3, 1, 64, 4, 4, 32, 1, 3, false)
+TPZ_CONV3D(3, 1, 32, 2, 4, 32, 1, 3, false)
+TPZ_CONV3D(3, 1, 48, 2, 4, 32, 1, 3, false)
+TPZ_CONV3D(3, 1, 64, 2, 4, 32, 1, 3, false)
 TPZ_CONV3D(3, 1, 96, 2, 4, 32, 1, 3, false)
 TPZ_CONV3D(7, 1, 16, 4, 4, 32, 1, 7, true)
 TPZ_CONV3D(7, 1, 48, 4, 4, 32, 1, 7, true)

@@ -1,6 +1,6 @@
 // 1x1 projections (ResidA.proj) and the single-input-channel stems (k-group = 4 kx taps).
 #include "conv_registry.h"
-TPZ_CONV2D(1, 1, 64, 16, 32, 4, 1, false)
+TPZ_CONV2D(1, 1, 64, 16, 32, 2, 1, false)
 TPZ_CONV2D(1, 1, 128, 8, 32, 4, 1, false)
 TPZ_CONV2D(7, 1, 32, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 48, 16, 32, 1, 7, true)

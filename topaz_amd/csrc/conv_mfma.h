@@ -80,14 +80,15 @@ struct ConvCfg {
     static constexpr int KXG = CIN1 ? KP / 4 : K;             // MFMA k-steps per tap row
     static constexpr int ITD = TD + KZ - 1;
     static constexpr int ITH = TH + K - 1;
-    static constexpr int ITW = TW + (KP - 1) * D;
+    // +3: the tile's x origin is moved left to a multiple of 4 pixels (16-byte DMA granules, see kernel)
+    static constexpr int ITW = (TW + (KP - 1) * D + 3 + 3) / 4 * 4;
     static constexpr int RS = ITW;
     static constexpr int PS = ITH * RS;             // plane stride
     static constexpr int TILE_ELEMS = ITD * PS;
     // channel stride == 16 (mod 32): the two 16-lane halves of a ds_read_b32 group hit disjoint banks
     static constexpr int CS = CIN1 ? TILE_ELEMS : (((TILE_ELEMS - 16 + 31) / 32) * 32 + 16);
     static constexpr int NCH = CIN1 ? 1 : 4 * KG;
-    static constexpr int IN_BUF = ((NCH * CS + 255) / 256) * 256;     // floats per input buffer (DMA granule 256)
+    static constexpr int IN_BUF = ((NCH * CS + 1023) / 1024) * 1024;  // floats per input buffer (DMA granule 256 x 16 B)
     static constexpr int NROWS = KZ * K;            // tap rows (kz, ky)
     static constexpr int SPG = NROWS / RPS;         // stages per channel chunk
     static constexpr int STEPS = (CIN1 ? 1 : KG) * RPS * KXG;         // MFMA k-steps per stage
@@ -136,8 +137,8 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 }
 
 // ABL: timing-ablation switches used by tools/conv_ablate.hip only (production kernels use ABL = 0):
-//   1 no wave priority   2 skip the per-stage DMA issue   4 skip the per-stage barrier
-//   8 fragment loads only for the first step of a stage (operands reused)   16 setprio on even slots instead
+//   2 skip the per-stage DMA issue   4 skip the per-stage barrier
+//   8 fragment loads only for the first step of a stage (operands reused)   16 static wave-slot priority
 template <class C, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int K = C::K, D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
@@ -151,13 +152,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // Two workgroups share a CU (two waves per SIMD, one from each).  Identical code makes them run in
-    // lockstep -- both in their DMA-issue / barrier phases at once, leaving the matrix pipe idle ~25 %.
-    // A static priority derived from the hardware wave slot (HW_REG_HW_ID.WAVE_ID, bit 0) breaks the
-    // symmetry: the odd slot's MFMAs always win arbitration, the even slot's fill every gap.
-    {
-        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // WAVE_ID[3:0]
-        if constexpr (!(ABL & 1)) { if (hw_id & 1u) __builtin_amdgcn_s_setprio(2); }
+    // (A static s_setprio split between the two co-resident workgroups was measured: neutral on the
+    //  MT=128 tiles, -10 % on MT=64 -- tools/conv_ablate.hip bit 16 re-enables it for experiments.)
+    if constexpr ((ABL & 16) != 0) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.WAVE_ID
+        if (hw_id & 1u) __builtin_amdgcn_s_setprio(2);
     }
 
     // ---- tile coordinates. y (and z) tiles are polyphase: row i of the tile is y0 + i*D.
@@ -166,10 +165,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int y0 = (ty / D) * (C::TH * D) + (ty % D);
     const int z0 = (C::DIMS == 3) ? (tz / D) * (C::TD * D) + (tz % D) : 0;
     const int x0 = blockIdx.x * C::TW;
-    const int ybase = y0 - a.pad, xbase = x0 - a.pad, zbase = (C::DIMS == 3) ? z0 - a.pad : 0;
+    // The LDS tile starts PADA = roundup4(pad) pixels left of x0, so every 4-float LDS granule maps to a
+    // 16-byte aligned global run when the row pitch is a multiple of 4 floats; B reads shift by PADA - pad.
+    const int pada = (a.pad + 3) & ~3;
+    const int xshift = pada - a.pad;
+    const int ybase = y0 - a.pad, xbase = x0 - pada, zbase = (C::DIMS == 3) ? z0 - a.pad : 0;
 
     // per-lane LDS read offsets (floats)
-    const int b_lane = (C::CIN1 ? (l4 * D + l15) : (l4 * C::CS + l15)) +
+    const int b_lane = xshift + (C::CIN1 ? (l4 * D + l15) : (l4 * C::CS + l15)) +
                        (C::IN_PLANE ? ((wave * C::RPW) / C::TH) * C::PS + ((wave * C::RPW) % C::TH) * C::RS
                                     : wave * (C::RPW / C::TH) * C::PS);
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win) || (a.D1 != a.Din);
@@ -182,15 +185,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // depend on the chunk, so they are computed ONCE per source tensor and kept in registers: the
     // per-stage issue is one 64-bit add + one global_load_lds per element.  off < 0: padding or outside
     // the image -> the element is fetched from the global zero word.
-    constexpr int NI = C::IN_BUF / 256;
-    constexpr unsigned OOB = 0xffffffffu;  // table entry of an element outside the image (zero-filled)
-    // Source byte offsets (relative to the chunk's first channel) of all IN_BUF elements.  They do not
-    // depend on the chunk, so they are computed once per source tensor into an LDS table (keeping them in
-    // VGPRs next to 128 accumulators made hipcc spill); each stage re-reads its NI entries.
+    constexpr int NI = C::IN_BUF / 256;    // 4-byte DMA pieces per thread and chunk (fallback mode)
+    constexpr int NI4 = C::IN_BUF / 1024;  // 16-byte DMA pieces per thread and chunk
+    constexpr unsigned OOB = 0xffffffffu;  // table entry of an element / granule outside the image (zero-filled)
+    // Source byte offsets (relative to the chunk's first channel) of the LDS image.  They do not depend on
+    // the chunk, so they are computed once per source tensor into an LDS table (keeping them in VGPRs next
+    // to 128 accumulators made hipcc spill); each stage re-reads its entries.
+    //   x4 mode: one entry per 4-float granule.  Needs rows that start 16-byte aligned and a width that is
+    //            a multiple of 4 (then a granule is entirely inside or outside the image) and no upsampling.
+    //   x1 mode: one entry per float (any geometry; nearest-upsampled sources).
+    bool x4mode = false;
     auto compute_offsets = [&](bool second) {
+        const float* p = second ? a.in2 : a.in;
+        const long long cs = second ? a.cs2 : a.cs1, ps = second ? a.ps2 : a.ps1;
+        const int pitch = second ? a.pitch2 : a.pitch1;
+        x4mode = ((a.Win | pitch) % 4 == 0) && (cs % 4 == 0) && (ps % 4 == 0) && (((size_t)p & 15) == 0) &&
+                 (second || !ups);
+        const int n = x4mode ? NI4 : NI;
 #pragma unroll 1
-        for (int i = 0; i < NI; ++i) {
-            const int e = i * 256 + tid;
+        for (int i = 0; i < n; ++i) {
+            const int g = i * 256 + tid;
+            const int e = x4mode ? 4 * g : g;
             const int c = e / C::CS;
             const int rem = e - c * C::CS;
             const int zz = rem / C::PS;
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int x = rem2 - r * C::RS;
             const int gy = ybase + r * D, gx = xbase + x;
             const int gz = (C::DIMS == 3) ? zbase + zz * D : 0;
-            unsigned off = 0;              // LDS padding elements are never read: they fetch the chunk's first word
+            unsigned off = 0;              // LDS padding is never read: it fetches the chunk's first words
             if (rem < C::TILE_ELEMS && c < C::NCH) {
                 if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win && (unsigned)gz < (unsigned)a.Din) {
                     long long o;
@@ -219,35 +234,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     off = OOB;
                 }
             }
-            lds_tab[e] = off;              // read back by the same thread only
+            lds_tab[g] = off;              // read back by the same thread only
         }
     };
     // chunks [0, chunks1) read `in`, the rest read `in2` (the host guarantees Cin1 % NCH == 0 with a concat)
     const int chunks1 = (a.in2 != nullptr) ? a.Cin1 / C::NCH : a.n_chunks;
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;     // LDS byte address of the dynamic region
     auto issue_input = [&](int ch, int buf) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + wave * 64) * 4u);
         const bool second = ch >= chunks1;
         const void* base = uniform_ptr(second ? a.in2 + (long long)(ch - chunks1) * C::NCH * a.cs2
                                               : a.in + (long long)ch * C::NCH * a.cs1);
         const void* zbase = uniform_ptr(a.zeros);
         const int c_left = a.Cin - ch * C::NCH;      // channels of this chunk that exist (>= NCH except in the last)
-        unsigned off[NI];
-        bool any_oob = false;
+        if (x4mode) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + wave * 256) * 4u);
+            unsigned off[NI4];
+            bool any_oob = false;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            off[i] = lds_tab[i * 256 + tid];
-            if (c_left < C::NCH && (i * 256 + tid) / C::CS >= c_left) off[i] = OOB;
-            any_oob |= (off[i] == OOB);
-        }
-        if (!__any(any_oob)) {
+            for (int i = 0; i < NI4; ++i) {
+                off[i] = lds_tab[i * 256 + tid];
+                if (c_left < C::NCH && (4 * (i * 256 + tid)) / C::CS >= c_left) off[i] = OOB;
+                any_oob |= (off[i] == OOB);
+            }
+            if (!__any(any_oob)) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) glds_b32(off[i], base, dst + i * 1024);
+                for (int i = 0; i < NI4; ++i) glds_b128(off[i], base, dst + i * 4096);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI4; ++i) {
+                    if (off[i] != OOB) glds_b128(off[i], base, dst + i * 4096);
+                    else glds_b128(0u, zbase, dst + i * 4096);
+                }
+            }
         } else {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + wave * 64) * 4u);
+#pragma unroll 1
+            for (int i0 = 0; i0 < NI; i0 += 8) {        // batches of 8 keep the register footprint small
+                unsigned off[8];
+                bool any_oob = false;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                if (off[i] != OOB) glds_b32(off[i], base, dst + i * 1024);
-                else glds_b32(0u, zbase, dst + i * 1024);
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k;
+                    off[k] = i < NI ? lds_tab[i * 256 + tid] : 0u;
+                    if (c_left < C::NCH && (i * 256 + tid) / C::CS >= c_left) off[k] = OOB;
+                    any_oob |= (off[k] == OOB);
+                }
+                const bool slow = __any(any_oob);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k;
+                    if (i < NI) {
+                        if (!slow || off[k] != OOB) glds_b32(off[k], base, dst + i * 1024);
+                        else glds_b32(0u, zbase, dst + i * 1024);
+                    }
+                }
             }
         }
     };
