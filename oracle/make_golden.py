@@ -231,8 +231,61 @@ def denoise3d():
     save('denoise3d_unet3d_nf8', tomo=tomo, p32_16=y, small=small, small_whole=y_whole, **sd_arrays(net))
 
 
+def cli():
+    """files either side of the path: MRC in, pick tables / denoised MRC out (reference CLI + file drivers)"""
+    import io
+    import contextlib
+    import shutil
+    import tempfile
+    from topaz import mrc
+    import topaz.commands.extract as cmd_extract     # topaz.main imports train -> torchvision (absent)
+
+    def topaz_extract(argv):
+        cmd_extract.main(cmd_extract.add_arguments().parse_args(argv))
+    from topaz.denoise import Denoise, Denoise3D, denoise_stream, denoise_tomogram_stream
+    from topaz.denoising.models import UDenoiseNet3D
+    tmp = tempfile.mkdtemp()
+    cli_dir = os.path.join(OUT, 'cli')
+    os.makedirs(cli_dir, exist_ok=True)
+    try:
+        for name, seed in (('mic_a', 61), ('mic_b', 62)):
+            x = image(seed, 160, 200)
+            with open(os.path.join(tmp, name + '.mrc'), 'wb') as f:
+                mrc.write(f, x[np.newaxis], ax=1.5, ay=1.5, az=1.0)
+            shutil.copy(os.path.join(tmp, name + '.mrc'), os.path.join(cli_dir, name + '.mrc'))
+        mics = [os.path.join(tmp, 'mic_a.mrc'), os.path.join(tmp, 'mic_b.mrc')]
+        # topaz extract (single TSV, coord format) and per-micrograph star files
+        topaz_extract(['-m', 'resnet8_u32', '-r', '8', '-d', '-1', '-o', os.path.join(tmp, 'picks.txt')] + mics)
+        shutil.copy(os.path.join(tmp, 'picks.txt'), os.path.join(cli_dir, 'extract_picks.txt'))
+        os.makedirs(os.path.join(tmp, 'out', 'COORDS'), exist_ok=True)   # the reference never creates it (SURVEY P8)
+        topaz_extract(['-m', 'resnet8_u32', '-r', '8', '-t', '-3', '-x', '2', '-d', '-1', '--per-micrograph',
+                       '--format', 'star', '-o', os.path.join(tmp, 'out', 'x'), mics[0]])
+        shutil.copy(os.path.join(tmp, 'out', 'COORDS', 'mic_a.star'), os.path.join(cli_dir, 'extract_mic_a.star'))
+        # denoise_stream with the v0.2.1 U-Net (the CLI itself can only load the missing `unet` blob)
+        denoise_stream(mics[:1], os.path.join(tmp, 'den'), format='mrc', suffix='', models=[Denoise('unet-v0.2.1')],
+                       deconvolve=False, patch_size=96, padding=24, normalize=False)
+        shutil.copy(os.path.join(tmp, 'den', 'mic_a.mrc'), os.path.join(cli_dir, 'denoise_mic_a.mrc'))
+        # a small tomogram through denoise_tomogram_stream with a seeded 3-D net saved the way the CLI loads it
+        torch.manual_seed(71)
+        net = UDenoiseNet3D(nf=8, base_width=7)
+        torch.save(net.state_dict(), os.path.join(cli_dir, 'unet3d_nf8_state.sav'))
+        dn = Denoise3D.__new__(Denoise3D)
+        dn.model, dn.device, dn.dims, dn.use_cuda = net.eval(), torch.device('cpu'), 3, False
+        tomo = (np.random.RandomState(72).randn(36, 40, 44)).astype(np.float32)
+        with open(os.path.join(tmp, 'tomo.mrc'), 'wb') as f:
+            mrc.write(f, tomo)
+        shutil.copy(os.path.join(tmp, 'tomo.mrc'), os.path.join(cli_dir, 'tomo.mrc'))
+        denoise_tomogram_stream([os.path.join(tmp, 'tomo.mrc')], dn, os.path.join(tmp, 'den3'), gaus=0, patch_size=32,
+                                padding=16, verbose=False)
+        shutil.copy(os.path.join(tmp, 'den3', 'tomo.mrc'), os.path.join(cli_dir, 'denoise3d_tomo.mrc'))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for fn in sorted(os.listdir(cli_dir)):
+        print('cli/' + fn, os.path.getsize(os.path.join(cli_dir, fn)))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d']
+    which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d', 'cli']
     torch.set_num_threads(8)
     for w in which:
         globals()[w]()

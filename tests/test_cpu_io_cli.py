@@ -1,0 +1,122 @@
+"""CPU checks of the rows either side of the hot path: MRC I/O, table writers, CLI flag surface."""
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+
+CLI = os.path.join(GOLDEN, 'cli')
+
+
+def test_mrc_parse_and_rewrite_is_byte_identical():
+    from topaz_amd import mrc
+    for name in ('mic_a.mrc', 'tomo.mrc', 'denoise_mic_a.mrc'):
+        content = open(os.path.join(CLI, name), 'rb').read()
+        arr, header, ext = mrc.parse(content)
+        assert header.mode == 2 and arr.dtype == np.float32
+        assert arr.shape == ((header.ny, header.nx) if header.nz == 1 else (header.nz, header.ny, header.nx))
+        buf = io.BytesIO()
+        mrc.write(buf, arr if arr.ndim == 3 else arr[np.newaxis], header=header, extended_header=ext)
+        assert buf.getvalue() == content
+    # a header synthesised by write() equals what the reference wrote for the same array
+    content = open(os.path.join(CLI, 'tomo.mrc'), 'rb').read()
+    arr, header, _ = mrc.parse(content)
+    buf = io.BytesIO()
+    mrc.write(buf, arr)
+    assert buf.getvalue() == content
+    content = open(os.path.join(CLI, 'mic_a.mrc'), 'rb').read()
+    arr, header, _ = mrc.parse(content)
+    buf = io.BytesIO()
+    mrc.write(buf, arr[np.newaxis], ax=1.5, ay=1.5, az=1.0)
+    assert buf.getvalue() == content
+    assert (header.xlen, header.ylen, header.zlen) == (1.5, 1.5, 1.0) and header.mapc == 1 and header.nx == 200
+
+
+def test_mrc_modes_and_float16_upcast(tmp_path):
+    from topaz_amd import mrc
+    from topaz_amd.utils.image import load_image
+    x = (np.arange(12 * 10).reshape(12, 10) % 7).astype(np.int16)
+    h = mrc.make_header((1, 12, 10), (1, 1, 1), (0, 0, 0), dtype=np.int16)
+    p = tmp_path / 'i16.mrc'
+    p.write_bytes(mrc.header_struct.pack(*list(h)) + x.tobytes())
+    y = load_image(str(p), make_image=False, return_header=False)
+    assert y.dtype == np.int16 and np.array_equal(y, x)
+    h16 = h._replace(mode=12)
+    p2 = tmp_path / 'f16.mrc'
+    p2.write_bytes(mrc.header_struct.pack(*list(h16)) + x.astype(np.float16).tobytes())
+    y2, hdr, ext = load_image(str(p2), make_image=False)
+    assert y2.dtype == np.float32 and hdr.mode == 12 and ext == b''
+
+
+def test_write_table_formats_match_reference_files():
+    from topaz_amd.utils.files import write_table
+    ref = open(os.path.join(CLI, 'extract_mic_a.star')).read()
+    rows = [l.split('\t') for l in ref.strip().split('\n')[6:]]
+    t = pd.DataFrame({'image_name': 'mic_a', 'x_coord': [int(r[2]) for r in rows], 'y_coord': [int(r[3]) for r in rows],
+                      'score': np.asarray([float(r[0]) for r in rows], dtype=np.float32)})
+    buf = io.StringIO()
+    write_table(buf, t, format='star', image_ext='.mrc')
+    assert buf.getvalue() == ref
+    buf = io.StringIO()
+    write_table(buf, t, format='coord')
+    assert buf.getvalue().split('\n')[0] == 'image_name\tx_coord\ty_coord\tscore'
+    buf = io.StringIO()
+    write_table(buf, t, format='box', boxsize=10)
+    assert buf.getvalue().split('\n')[0] == f'{t.x_coord[0] - 5}\t{t.y_coord[0] - 5}\t10\t10'
+    buf = io.StringIO()
+    write_table(buf, t, format='json')
+    import json
+    assert json.loads(buf.getvalue())['boxes'][0] == [int(t.x_coord[0]), int(t.y_coord[0]), 'manual']
+
+
+def test_cli_flag_surface_and_defaults():
+    """same style as the reference's test/test_commands_simple.py: build each parser, parse tutorial argv"""
+    from topaz_amd.commands import denoise, denoise3d, extract, segment
+    a = extract.add_arguments().parse_args(['-r', '14', '-x', '8', '-o', 'out.txt', 'a.mrc', 'b.mrc'])
+    assert (a.model, a.threshold, a.device, a.format, a.dims, a.radius, a.up_scale, a.down_scale, a.patch_size) == \
+        ('resnet16', -6, 0, 'coord', 2, 14, 8.0, 1, 0)
+    assert a.paths == ['a.mrc', 'b.mrc'] and not a.per_micrograph and a.num_workers == 0
+    d = denoise.add_arguments().parse_args(['-o', 'den/', 'm.mrc'])
+    assert (d.model, d.patch_size, d.patch_padding, d.format_, d.device, d.lowpass, d.gaussian) == \
+        (['unet'], 1024, 500, 'mrc', 0, 1, 0)
+    t = denoise3d.add_arguments().parse_args(['-o', 'den3/', 'v.mrc'])
+    assert (t.model, t.patch_size, t.patch_padding, t.device, t.gaussian) == ('unet-3d', 96, 48, -2, 0)
+    s = segment.add_arguments().parse_args(['-o', 'seg/', 'm.mrc'])
+    assert (s.model, s.device, s.patch_size) == ('resnet16', 0, None)
+
+
+def test_main_dispatch_and_at_file_expansion(tmp_path, capsys):
+    from topaz_amd import main as tmain
+    argfile = tmp_path / 'args.txt'
+    argfile.write_text('extract\n--help\n')
+    with pytest.raises(SystemExit) as e:
+        tmain.main(['@' + str(argfile)])
+    assert e.value.code == 0
+    assert 'radius of the regions to extract' in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        tmain.main(['--version'])
+
+
+def test_missing_default_blobs_fail_loudly():
+    from topaz_amd.model.factory import load_model
+    with pytest.raises(RuntimeError, match='not packaged'):
+        load_model('resnet16')
+    from topaz_amd.denoising.models import load_model as ld
+    with pytest.raises(RuntimeError, match='not packaged'):
+        ld('unet')
+
+
+def test_average_precision_and_matching():
+    from topaz_amd.metrics import average_precision
+    from topaz_amd.extract import match_coordinates
+    hits = np.array([1, 0, 1, 1, 0], dtype=np.float32)
+    pred = np.array([0.9, 0.8, 0.7, 0.7, 0.1], dtype=np.float32)
+    # buckets: {0.9: 1/1}, {0.8: 1/2}, {0.7 x2: 3/4}, {0.1: 3/5} -> AP = (1*1 + .5*0 + .75*2 + .6*0)/3
+    assert abs(average_precision(hits, pred) - (1.0 + 1.5) / 3) < 1e-12
+    t = np.array([[10, 10], [50, 50]])
+    p = np.array([[11, 10], [80, 80], [49, 52]])
+    a, d = match_coordinates(t, p, 5)
+    assert a.tolist() == [1, 0, 1] and abs(d[0] - 1) < 1e-9

@@ -126,3 +126,105 @@ def denoise_image(mic: np.ndarray, models: List[Denoise], lowpass=1, cutoff=0, g
     else:
         out = std * out + mu
     return out
+
+
+# ---- file-level drivers (denoise.py:419-557) ----------------------------------------------------------
+def denoise_stack(path: str, output_path: str, models: List[Denoise], lowpass: float = 1, pixel_cutoff: float = 0,
+                  gaus=None, inv_gaus=None, deconvolve: bool = True, deconv_patch: int = 1, patch_size: int = 1024,
+                  padding: int = 500, normalize: bool = True, use_cuda: bool = True):
+    from . import mrc
+    with open(path, 'rb') as f:
+        content = f.read()
+    stack, header, extended_header = mrc.parse(content)
+    print('# denoising stack with shape:', stack.shape, file=sys.stderr)
+    denoised = np.zeros_like(stack)
+    for i in range(len(stack)):
+        denoised[i] = denoise_image(stack[i], models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
+                                    deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size,
+                                    padding=padding, normalize=normalize, use_cuda=use_cuda)
+        print('# {} of {} completed.'.format(i + 1, len(stack)), file=sys.stderr, end='\r')
+    print('', file=sys.stderr)
+    print('# writing to', output_path, file=sys.stderr)
+    with open(output_path, 'wb') as f:
+        mrc.write(f, denoised, header=header, extended_header=extended_header)
+    return denoised
+
+
+def denoise_stream(micrographs: List[str], output_path: str, format: str = 'mrc', suffix: str = '',
+                   models: List[Denoise] = None, lowpass: float = 1, pixel_cutoff: float = 0, gaus=None, inv_gaus=None,
+                   deconvolve: bool = True, deconv_patch: int = 1, patch_size: int = 1024, padding: int = 500,
+                   normalize: bool = True, use_cuda: bool = True):
+    """With WORLD_SIZE > 1 (torchrun) rank r denoises micrographs r, r+world, ... and writes its own files."""
+    from . import parallel
+    from .utils.image import load_image, save_image
+    rank, _, world = parallel.init_from_env()
+    total = len(micrographs)
+    denoised = []
+    if output_path is not None and output_path != '':
+        os.makedirs(output_path, exist_ok=True)
+    for count, idx in enumerate(parallel.shard_indices(total, rank, world)):
+        path = micrographs[idx]
+        name, _ = os.path.splitext(os.path.basename(path))
+        image = load_image(path, make_image=False)
+        image, header, extended_header = image if type(image) is tuple else (image, None, None)
+        mic = denoise_image(image, models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
+                            deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size, padding=padding,
+                            normalize=normalize, use_cuda=use_cuda)
+        denoised.append(mic)
+        if not output_path:
+            if suffix == '' or suffix is None:
+                suffix = '.denoised'
+            no_ext, ext = os.path.splitext(path)
+            outpath = no_ext + suffix + '.' + format
+        else:
+            outpath = output_path + os.sep + name + suffix + '.' + format
+        save_image(mic, outpath, header=header, extended_header=extended_header)
+        print(f'# {count + 1} of {total} completed.', file=sys.stderr, end='\r')
+    print('', file=sys.stderr)
+    return denoised
+
+
+def denoise_tomogram(path: str, model: Denoise3D, outdir: str = None, suffix: str = '', patch_size: int = 96,
+                     padding: int = 48, volume_num: int = 1, total_volumes: int = 1, gaus=None, verbose: bool = True):
+    from . import mrc
+    name = os.path.basename(path)
+    with open(path, 'rb') as f:
+        content = f.read()
+    tomo, header, extended_header = mrc.parse(content)
+    tomo = tomo.astype(np.float32)
+    denoised = model.denoise(tomo, patch_size=patch_size, padding=padding, batch_size=1, volume_num=volume_num,
+                             total_volumes=total_volumes, verbose=verbose)
+    # (the reference filters `tomo`, not `denoised`, and writes `denoised`: denoise.py:509,528-529)
+    tomo = gaus.apply(tomo) if gaus is not None else tomo
+    if not outdir:
+        if suffix == '':
+            suffix = '.denoised'
+        no_ext, ext = os.path.splitext(path)
+        outpath = no_ext + suffix + ext
+    else:
+        no_ext, ext = os.path.splitext(name)
+        outpath = outdir + os.sep + no_ext + suffix + ext
+    header = header._replace(mode=2, amin=denoised.min(), amax=denoised.max(), amean=denoised.mean())
+    with open(outpath, 'wb') as f:
+        mrc.write(f, denoised, header=header, extended_header=extended_header)
+    return tomo
+
+
+def denoise_tomogram_stream(volumes: List[str], model: Denoise3D, output_path: str, suffix: str = '', gaus: float = None,
+                            patch_size: int = 96, padding: int = 48, verbose: bool = True, use_cuda: bool = True):
+    from . import parallel
+    rank, _, world = parallel.init_from_env()
+    total = len(volumes)
+    denoised = []
+    if output_path is not None and output_path != '':
+        os.makedirs(output_path, exist_ok=True)
+    if gaus is not None and gaus > 0:
+        raise NotImplementedError('3-D Gaussian post-filter: the reference applies it to the input and discards it '
+                                  '(denoise.py:509); not implemented')
+    for count, idx in enumerate(parallel.shard_indices(total, rank, world)):
+        volume = denoise_tomogram(volumes[idx], model, outdir=output_path, suffix=suffix, patch_size=patch_size,
+                                  padding=padding, volume_num=idx + 1, total_volumes=total, gaus=None, verbose=verbose)
+        denoised.append(volume)
+        print(f'# {count + 1} of {total} tomograms denoised.', file=sys.stderr, end='\r')
+    print('', file=sys.stderr)
+    return denoised

@@ -1,0 +1,77 @@
+"""Pick-table writers, restating topaz/utils/files.py write_table (:242-268), write_via_csv (:109-146),
+topaz/utils/conversions.py coordinates_to_boxes (:83-97), coordinates_to_eman2_json (:131-139),
+coordinates_to_star (:173-192) and topaz/utils/star.py write (:91-98)."""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+import pandas as pd
+
+_STAR_NAMES = {'score': 'AutopickFigureOfMerit', 'image_name': 'MicrographName', 'x_coord': 'CoordinateX',
+               'y_coord': 'CoordinateY', 'voltage': 'Voltage', 'detector_pixel_size': 'DetectorPixelSize',
+               'magnification': 'Magnification', 'amplitude_contrast': 'AmplitudeContrast'}
+
+
+def coordinates_to_boxes(coords, box_width, box_height):
+    x, y = coords[:, 0], coords[:, 1]
+    bw = np.array([box_width] * len(x), dtype=np.int32)
+    bh = np.array([box_height] * len(x), dtype=np.int32)
+    return np.stack([x - bw // 2, y - bh // 2, bw, bh], 1)
+
+
+def coordinates_to_star(table, image_ext=''):
+    table = table.copy()
+    for k, v in _STAR_NAMES.items():
+        if k in table.columns:
+            table[v] = table[k]
+            table = table.drop(k, axis=1)
+    table['MicrographName'] = table['MicrographName'].apply(lambda x: x + image_ext)
+    return table
+
+
+def write_star(table, f):
+    print('data_images', file=f)
+    print('loop_', file=f)
+    for i, name in enumerate(table.columns):
+        print('_rln' + name + ' #' + str(i + 1), file=f)
+    table.to_csv(f, sep='\t', index=False, header=False)
+
+
+def write_via_csv(path, table):
+    filename = table['image_name'].apply(lambda x: x + '.png')
+    via = pd.DataFrame({'filename': filename})
+    via['file_size'] = -1
+    via['file_attributes'] = '{}'
+    via['region_count'] = 0
+    via['region_id'] = 0
+    for im, group in table.groupby('image_name'):
+        where = via['filename'] == im + '.png'
+        via.loc[where, 'region_count'] = len(group)
+        via.loc[where, 'region_id'] = np.arange(len(group))
+    via['region_shape_attributes'] = ['{{"name":"point","cx":{},"cy":{}}}'.format(table['x_coord'].iloc[i],
+                                                                                 table['y_coord'].iloc[i])
+                                      for i in range(len(table))]
+    if 'score' in table.columns:
+        via['region_attributes'] = ['{{"score":"{}"}}'.format(table['score'].iloc[i]) for i in range(len(table))]
+    else:
+        via['region_attributes'] = '{}'
+    via.to_csv(path, index=False)
+
+
+def write_table(f, table, format='auto', boxsize=0, image_ext=''):
+    if format == 'box':
+        xy = table[['x_coord', 'y_coord']].values.astype(np.int32)
+        pd.DataFrame(coordinates_to_boxes(xy, boxsize, boxsize)).to_csv(f, sep='\t', header=False, index=False)
+    elif format == 'json':
+        xy = table[['x_coord', 'y_coord']].values.astype(int)
+        json.dump({'boxes': [[int(x), int(y), 'manual'] for x, y in xy]}, f, indent=0)
+    elif format == 'star':
+        write_star(coordinates_to_star(table, image_ext=image_ext), f)
+    elif format == 'csv':
+        write_via_csv(f, table)
+    else:
+        columns = ['image_name', 'x_coord', 'y_coord']
+        if 'score' in table.columns:
+            columns.append('score')
+        table[columns].to_csv(f, sep='\t', index=False)
