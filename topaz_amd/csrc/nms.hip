@@ -38,26 +38,64 @@ __device__ __forceinline__ uint64_t prio_key(float f, uint32_t idx) {
 __global__ __launch_bounds__(256) void nms_mark_kernel(const float* __restrict__ score, size_t n, float thr,
                                                        uint8_t* __restrict__ status, uint32_t* __restrict__ cand,
                                                        unsigned int* __restrict__ counters) {
-    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
-        const size_t i = base + threadIdx.x;
-        bool is_c = false;
-        if (i < n) {
-            const float s = score[i];
-            is_c = !(s <= thr);
-            status[i] = is_c ? ST_UNDECIDED : ST_NONE;
+    // 1024 elements per block iteration; one atomic per iteration (wave ballots + LDS prefix over the 4 waves)
+    __shared__ unsigned int wave_cnt[4];
+    __shared__ unsigned int block_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 1024; base < n; base += (size_t)gridDim.x * 1024) {
+        bool is_c[4];
+        unsigned int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = base + (size_t)k * 256 + threadIdx.x;
+            is_c[k] = false;
+            if (i < n) {
+                const float s = score[i];
+                is_c[k] = !(s <= thr);
+                status[i] = is_c[k] ? ST_UNDECIDED : ST_NONE;
+            }
+            mine += is_c[k] ? 1u : 0u;
         }
-        const unsigned long long m = __ballot(is_c);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            unsigned int pos = 0;
-            if (lane == 0) pos = atomicAdd(&counters[0], (unsigned int)__popcll(m));
-            pos = __shfl(pos, 0, 64);
-            if (is_c) cand[pos + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        // exclusive prefix of `mine` inside the wave
+        unsigned int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
         }
+        if (lane == 63) wave_cnt[wv] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            block_base = tot ? atomicAdd(&counters[0], tot) : 0u;
+        }
+        __syncthreads();
+        unsigned int pos = block_base + (incl - mine);
+        for (int w = 0; w < wv; ++w) pos += wave_cnt[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (is_c[k]) cand[pos++] = (uint32_t)(base + (size_t)k * 256 + threadIdx.x);
+        __syncthreads();
     }
 }
 
-// one relaxation sweep over the candidate list (2-D)
+// One relaxation sweep over the candidate list (2-D).
+//   pull: an undecided p looks for ANY higher-priority candidate among its possible suppressors that is not
+//         (yet) SUPPRESSED; the first one found blocks p this sweep (if that neighbour is SELECTED its push
+//         will suppress p, if it is UNDECIDED p has to wait) -- so most candidates stop after a few probes.
+//   push: a p with no such neighbour is SELECTED and immediately marks every lower-priority candidate of
+//         Supp(p) SUPPRESSED (including the column-0-of-the-next-row cells of the right-edge quirk).
+__device__ __forceinline__ bool nms2d_blocks(const float* __restrict__ score, const uint8_t* status, size_t rowb,
+                                             int x_lo, int x_hi, uint64_t kp) {
+    for (int qx = x_lo; qx <= x_hi; ++qx) {
+        const uint8_t st = status[rowb + qx];
+        if (st == ST_NONE || st == ST_SUPPRESSED) continue;
+        const uint32_t q = (uint32_t)(rowb + qx);
+        if (prio_key(score[q], q) > kp) return true;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void nms2d_iter_kernel(const float* __restrict__ score, int H, int W, int r,
                                                          const int* __restrict__ halfw, uint8_t* status,
                                                          const uint32_t* __restrict__ cand, unsigned int ncand,
@@ -68,53 +106,48 @@ __global__ __launch_bounds__(256) void nms2d_iter_kernel(const float* __restrict
         if (status[p] != ST_UNDECIDED) continue;
         const int py = (int)(p / (uint32_t)W), px = (int)(p % (uint32_t)W);
         const uint64_t kp = prio_key(score[p], p);
-        bool suppressed = false, blocked = false;
-        for (int dy = -r; dy <= r && !suppressed; ++dy) {
+        bool blocked = false;
+        // nearest rows first: dy = 0, -1, +1, -2, +2, ...
+        for (int k = 0; k <= 2 * r && !blocked; ++k) {
+            const int dy = (k & 1) ? -((k + 1) >> 1) : (k >> 1);
             const int qy = py + dy;
             if ((unsigned)qy >= (unsigned)H) continue;
             const int hw = halfw[dy + r];
-            const int x_lo = max(px - hw, 0), x_hi = min(px + hw, W - 1);
-            const size_t rowb = (size_t)qy * W;
-            for (int qx = x_lo; qx <= x_hi; ++qx) {
-                const uint8_t st = status[rowb + qx];
-                if (st == ST_NONE || st == ST_SUPPRESSED) continue;
-                const uint32_t q = (uint32_t)(rowb + qx);
-                if (prio_key(score[q], q) > kp) {
-                    if (st == ST_SELECTED) { suppressed = true; break; }
-                    blocked = true;
-                }
-            }
+            blocked = nms2d_blocks(score, status, (size_t)qy * W, max(px - hw, 0), min(px + hw, W - 1), kp);
         }
-        if (!suppressed && px == 0 && py >= 1) {
+        if (!blocked && px == 0 && py >= 1) {
             // right-edge wrap: picks near column W-1 of rows around py-1 suppress (py, 0)
-            for (int dy = -r; dy <= r && !suppressed; ++dy) {
-                const int qy = py - 1 + dy;            // q row; offset ii = -dy lands on row py-1
+            for (int dy = -r; dy <= r && !blocked; ++dy) {
+                const int qy = py - 1 + dy;
                 if ((unsigned)qy >= (unsigned)H) continue;
                 const int hw = halfw[dy + r];
-                // need W - qx <= hw  ->  qx >= W - hw
-                const int x_lo = max(W - hw, 0);
-                const size_t rowb = (size_t)qy * W;
-                for (int qx = x_lo; qx <= W - 1; ++qx) {
-                    const uint8_t st = status[rowb + qx];
-                    if (st == ST_NONE || st == ST_SUPPRESSED) continue;
-                    const uint32_t q = (uint32_t)(rowb + qx);
-                    if (prio_key(score[q], q) > kp) {
-                        if (st == ST_SELECTED) { suppressed = true; break; }
-                        blocked = true;
-                    }
-                }
+                if (hw >= 1) blocked = nms2d_blocks(score, status, (size_t)qy * W, max(W - hw, 0), W - 1, kp);
             }
         }
-        if (suppressed) status[p] = ST_SUPPRESSED;
-        else if (!blocked) status[p] = ST_SELECTED;
-        else ++remaining;
+        if (blocked) { ++remaining; continue; }
+        status[p] = ST_SELECTED;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int qy = py + dy;
+            if ((unsigned)qy >= (unsigned)H) continue;
+            const int hw = halfw[dy + r];
+            const size_t rowb = (size_t)qy * W;
+            const int x_hi = min(px + hw, W - 1);
+            for (int qx = max(px - hw, 0); qx <= x_hi; ++qx) {
+                const uint32_t q = (uint32_t)(rowb + qx);
+                if (status[q] == ST_UNDECIDED && prio_key(score[q], q) < kp) status[q] = ST_SUPPRESSED;
+            }
+            if (px + hw >= W && qy + 1 <= H - 1) {       // flat = qy*W + W  ==  (qy+1, 0)
+                const uint32_t q = (uint32_t)(rowb + W);
+                if (status[q] == ST_UNDECIDED && prio_key(score[q], q) < kp) status[q] = ST_SUPPRESSED;
+            }
+        }
     }
     // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) remaining += __shfl_xor(remaining, o, 64);
     if ((threadIdx.x & 63) == 0 && remaining) atomicAdd(&counters[1], remaining);
 }
 
-// one relaxation sweep (3-D, flat-index deltas with wrap-around)
+// one relaxation sweep (3-D, flat-index deltas with wrap-around; the delta set is symmetric)
 __global__ __launch_bounds__(256) void nms3d_iter_kernel(const float* __restrict__ score, long long n,
                                                          const int* __restrict__ deltas, int ndelta, uint8_t* status,
                                                          const uint32_t* __restrict__ cand, unsigned int ncand,
@@ -124,20 +157,21 @@ __global__ __launch_bounds__(256) void nms3d_iter_kernel(const float* __restrict
         const uint32_t p = cand[c];
         if (status[p] != ST_UNDECIDED) continue;
         const uint64_t kp = prio_key(score[p], p);
-        bool suppressed = false, blocked = false;
-        for (int d = 0; d < ndelta; ++d) {
+        bool blocked = false;
+        for (int d = 0; d < ndelta && !blocked; ++d) {
             const long long q = (long long)p + deltas[d];
             if (q < 0 || q >= n) continue;
             const uint8_t st = status[q];
             if (st == ST_NONE || st == ST_SUPPRESSED) continue;
-            if (prio_key(score[q], (uint32_t)q) > kp) {
-                if (st == ST_SELECTED) { suppressed = true; break; }
-                blocked = true;
-            }
+            blocked = prio_key(score[q], (uint32_t)q) > kp;
         }
-        if (suppressed) status[p] = ST_SUPPRESSED;
-        else if (!blocked) status[p] = ST_SELECTED;
-        else ++remaining;
+        if (blocked) { ++remaining; continue; }
+        status[p] = ST_SELECTED;
+        for (int d = 0; d < ndelta; ++d) {
+            const long long q = (long long)p + deltas[d];
+            if (q < 0 || q >= n) continue;
+            if (status[q] == ST_UNDECIDED && prio_key(score[q], (uint32_t)q) < kp) status[q] = ST_SUPPRESSED;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) remaining += __shfl_xor(remaining, o, 64);
     if ((threadIdx.x & 63) == 0 && remaining) atomicAdd(&counters[1], remaining);
@@ -251,7 +285,8 @@ static inline int nblocks(size_t n, int cap = 8192) {
 
 hipError_t nms_mark(const float* score, size_t n, float thr, uint8_t* status, uint32_t* cand, unsigned int* counters,
                     hipStream_t s) {
-    hipLaunchKernelGGL(nms_mark_kernel, dim3(nblocks(n)), dim3(256), 0, s, score, n, thr, status, cand, counters);
+    hipLaunchKernelGGL(nms_mark_kernel, dim3(nblocks((n + 3) / 4, 4096)), dim3(256), 0, s, score, n, thr, status, cand,
+                       counters);
     return hipGetLastError();
 }
 hipError_t nms2d_iter(const float* score, int H, int W, int r, const int* halfw, uint8_t* status,
