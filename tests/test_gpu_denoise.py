@@ -16,7 +16,7 @@ def _err(a, b, scale=1.0):
     return np.abs(a - b).max() / scale
 
 
-@pytest.mark.parametrize('name', ['unet-v0.2.1', 'unet-small', 'affine'])
+@pytest.mark.parametrize('name', ['unet-v0.2.1', 'unet-small', 'fcnn', 'affine'])
 def test_pretrained_vs_reference_golden(gpu_ctx, name):
     from topaz_amd.denoise import Denoise
     z = load_golden('denoise2d_pretrained')
@@ -92,3 +92,20 @@ def test_unet3d_nf48_tile_vs_oracle(gpu_ctx):
     t = np.random.RandomState(2001).randn(30, 40, 50).astype(np.float32) * 2 + 3
     ref = oden.denoise3d(sd, t, 32, 16)
     assert _err(d.denoise(t, 32, 16, verbose=False), ref, 2.0) <= ATOL
+
+
+def test_full_size_4096_default_patching_vs_oracle_patch(gpu_ctx):
+    """BASELINE size with the CLI-default patching (-s 1024 -p 500): the output inside one patch's centre must
+    equal the oracle's _denoise of that patch crop alone (patches are independent, denoise.py:307-322)."""
+    from topaz_amd.denoise import Denoise
+    x = (np.random.RandomState(1003).randn(4096, 4096) * 2 + 5).astype(np.float32)
+    d = Denoise('unet-v0.2.1')
+    y = d.denoise(x, patch_size=1024, padding=500)
+    assert y.shape == x.shape
+    sd = {k: v.numpy() for k, v in d.model.state_dict().items()}
+    import torch
+    for (i, j) in ((0, 0), (3072, 1024)):
+        si, ei, sj, ej = max(0, i - 500), min(4096, i + 1524), max(0, j - 500), min(4096, j + 1524)
+        ref = oden.denoise_whole('unet', oden.to_torch_sd(sd), torch.from_numpy(x[si:ei, sj:ej].copy()))
+        ref = ref[i - si:i - si + 1024, j - sj:j - sj + 1024]
+        assert _err(y[i:i + 1024, j:j + 1024], ref, 2.0) <= ATOL, (i, j)

@@ -102,3 +102,26 @@ def test_user_model_pickle(gpu_ctx, name):
     z = load_golden(f'score_{name}')
     m = load_model(os.path.join(GOLDEN, f'user_model_{name}.sav'))
     assert np.abs(_score(m, z['x0']) - z['y0']).max() <= ATOL
+
+
+def test_full_size_4096_windows_vs_oracle(gpu_ctx):
+    """BASELINE size (4096x4096): the filled net is translation equivariant with a 71-pixel receptive
+    field, so any window of the full-size score map must equal the oracle run on the window's own
+    crop (+35 halo, zero beyond the image).  Checks interior, edge and corner windows."""
+    from topaz_amd.model.factory import load_model
+    x = np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)
+    m = load_model('resnet8_u32')
+    y = _score(m, x)
+    assert y.shape == (4096, 4096)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    p = 35
+    for (y0, x0) in ((0, 0), (1900, 2100), (3840, 0), (3840, 3840), (777, 3840)):
+        h = w = 256
+        ys, xs = max(0, y0 - p), max(0, x0 - p)
+        ye, xe = min(4096, y0 + h + p), min(4096, x0 + w + p)
+        crop = x[ys:ye, xs:xe]
+        ref = oscoring.score('resnet8', sd, crop)
+        # rows/cols of the crop that are at the image border carry the reference's zero padding; rows cut
+        # inside the image are only valid `p` pixels away from the cut
+        ref_win = ref[y0 - ys:y0 - ys + h, x0 - xs:x0 - xs + w]
+        assert np.abs(y[y0:y0 + h, x0:x0 + w] - ref_win).max() <= ATOL, (y0, x0)

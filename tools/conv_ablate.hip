@@ -57,6 +57,17 @@ int bench(const char* name, int cin, int cout, int H) {
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
     RUN(16, "static priority on odd wave slots");
+    {
+        ConvArgs b = a;
+        b.stagger_first = 512;
+        // half a workgroup lifetime: n_stages*STEPS*MW*NW MFMAs * 32 cycles (x2 sharing, /2 half) in 8128-cycle sleeps
+        b.stagger_sleeps = (int)((long long)n_chunks * C::SPG * C::STEPS * C::MW * C::NW * 32 / 8128);
+        float ms = run<C, 0>(b, grid, 2);
+        printf("  %-44s %8.3f ms  %6.1f TF/s\n", "phase stagger (odd slot sleeps T/2 once)", ms, tf / (ms * 1e-3));
+        b.stagger_sleeps /= 2;
+        ms = run<C, 0>(b, grid, 2);
+        printf("  %-44s %8.3f ms  %6.1f TF/s\n", "phase stagger (T/4)", ms, tf / (ms * 1e-3));
+    }
     RUN(2, "no per-stage DMA issue");
     RUN(4, "no per-stage barrier");
     RUN(8, "no LDS fragment reads after step 0");

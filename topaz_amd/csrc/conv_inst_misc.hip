@@ -7,3 +7,5 @@ TPZ_CONV2D(7, 1, 48, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 64, 16, 32, 1, 7, true)
 TPZ_CONV2D(11, 1, 48, 16, 32, 1, 11, true)
 TPZ_CONV2D(11, 1, 64, 16, 32, 1, 11, true)
+// FCNN (DenoiseNet2, denoising/models.py:52-66): 11x11 64 -> 64, one tap row (11 k-steps) per stage
+TPZ_CONV2D(11, 1, 64, 16, 32, 1, 1, false)

@@ -56,6 +56,8 @@ struct ConvArgs {
     int n_chunks;             // channel chunks of NCH channels
     float slope;              // activation: v > 0 ? v : v*slope   (1.0 = identity, 0.0 = ReLU)
     int tiles_x, tiles_y, tiles_z;
+    int stagger_first;        // workgroups with a linear id below this belong to the first generation
+    int stagger_sleeps;       // s_sleep(127) repeats for the odd wave slot of the first generation (0 = off)
 };
 
 // PyTorch 'nearest' source index: min(floor(dst * (float)in/out), in-1)  
@@ -157,6 +159,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     if constexpr ((ABL & 16) != 0) {
         const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.WAVE_ID
         if (hw_id & 1u) __builtin_amdgcn_s_setprio(2);
+    }
+    // Phase stagger: the two workgroups sharing a CU start together and, running identical code, stay in
+    // lockstep -- both in their prologue / epilogue (no MFMA) at the same time, generation after generation.
+    // The workgroups of the FIRST generation that sit in the odd hardware wave slot wait half a workgroup
+    // lifetime once; from then on one workgroup's fixed costs overlap the other's MFMA phase.
+    if (a.stagger_sleeps > 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) < a.stagger_first) {
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (hw_id & 1u)
+            for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
     }
 
     // ---- tile coordinates. y (and z) tiles are polyphase: row i of the tile is y0 + i*D.

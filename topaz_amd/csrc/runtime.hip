@@ -350,6 +350,14 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
             return fail(ctx, "fused concat needs the first source's channels (%d) to be a multiple of %d", s1.C, ki.NCH);
         a.n_chunks = rt.n_chunks;
         a.cog_inner = rt.cog_inner;
+        {   // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
+            const long long wgs = (long long)((dst.W + ki.TW - 1) / ki.TW) * ((dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D);
+            if (wgs >= 4096) {
+                a.stagger_first = 512;
+                a.stagger_sleeps = (int)((long long)rt.n_chunks * ki.SPG * ki.STEPS * (ki.MT / 16) *
+                                         ((ki.TD * ki.TH / 4) * (ki.TW / 16)) * 32 / 8128 / 2);
+            }
+        }
         a.tiles_x = (dst.W + ki.TW - 1) / ki.TW;
         a.tiles_y = (dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
         a.tiles_z = L.dims == 3 ? (dst.D + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
