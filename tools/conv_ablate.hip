@@ -10,14 +10,14 @@ using namespace tpz;
 
 template <class C, int ABL>
 float run(const ConvArgs& a, dim3 grid, int iters) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C, ABL>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<C, 0, ABL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((conv_mfma_kernel<C, ABL>), grid, dim3(256), C::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<C, 0, ABL>), grid, dim3(256), C::LDS_BYTES, 0, a);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_kernel<C, ABL>), grid, dim3(256), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_mfma_kernel<C, 0, ABL>), grid, dim3(256), C::LDS_BYTES, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;

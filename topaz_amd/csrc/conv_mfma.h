@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace tpz {
 
@@ -141,7 +142,12 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // ABL: timing-ablation switches used by tools/conv_ablate.hip only (production kernels use ABL = 0):
 //   2 skip the per-stage DMA issue   4 skip the per-stage barrier
 //   8 fragment loads only for the first step of a stage (operands reused)   16 static wave-slot priority
-template <class C, int ABL = 0>
+// EPI selects the epilogue the kernel is compiled for (one lean, branch-free code path each):
+//   0 bias + activation            1 + residual add (ResidA skip)
+//   2 + residual + eval-BN affine  3 bias + activation + fused 1x1 head
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_RES_POST = 2, EPI_HEAD = 3 };
+
+template <class C, int EPI = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int K = C::K, D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -391,38 +397,47 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             if constexpr (!(ABL & 4)) __syncthreads();         // ... everyone's has; stage s buffers are free
         }
 
-        // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store
+        // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store.
+        // One predicate per 16-pixel fragment (not per element) and clamped channel indices keep the
+        // scattered loads of a fragment free of branches, so they are issued back to back.
         const size_t plane_out = (size_t)a.Hout * a.Wout;
         const size_t vol_out = plane_out * a.Dout;
         const size_t plane_res = (size_t)a.Hres * a.Wres;
         const size_t vol_res = plane_res * a.Dres;
+        const int co0 = cog * C::MT + l4 * 4;
+        const bool has_bias = a.bias != nullptr;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int trow = wave * C::RPW + n / NFC;             // tile row, z-major
             const int ti_z = trow / C::TH, ti_y = trow % C::TH;
             const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
             const int ox = x0 + (n % NFC) * 16 + l15;
-            const bool inb = (oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout);
+            if ((oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout)) {
+                const size_t pix_res = (size_t)(C::DIMS == 3 ? oz + a.res_crop : 0) * plane_res +
+                                       (size_t)(oy + a.res_crop) * a.Wres + (ox + a.res_crop);
+                const size_t pix_out = (size_t)oz * plane_out + (size_t)oy * a.Wout + ox;
 #pragma unroll
-            for (int m = 0; m < MW; ++m) {
+                for (int m = 0; m < MW; ++m) {
+                    float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = cog * C::MT + m * 16 + l4 * 4 + r;
-                    if (co < a.Cout && inb) {
-                        float v = acc[m][n][r];
-                        if (a.bias) v += a.bias[co];
-                        if (a.res) {
-                            const int c = a.res_crop;
-                            v += a.res[(size_t)co * vol_res + (size_t)(C::DIMS == 3 ? oz + c : 0) * plane_res +
-                                       (size_t)(oy + c) * a.Wres + (ox + c)];
-                        }
-                        if (a.post_scale) v = v * a.post_scale[co] + a.post_shift[co];
-                        v = v > 0.f ? v : v * a.slope;
-                        if (a.head_w) {
-                            hsum[n] += v * a.head_w[co];
-                        } else {
-                            if (a.norm_out) v = v * out_scale + out_shift;
-                            a.out[(size_t)co * vol_out + (size_t)oz * plane_out + (size_t)oy * a.Wout + ox] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + m * 16 + r;
+                        const int cc = co < a.Cout ? co : a.Cout - 1;          // clamped: loads stay in range
+                        v[r] = acc[m][n][r] + (has_bias ? a.bias[cc] : 0.f);
+                        if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) v[r] += a.res[(size_t)cc * vol_res + pix_res];
+                        if constexpr (EPI == EPI_RES_POST) v[r] = v[r] * a.post_scale[cc] + a.post_shift[cc];
+                        v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+                        if constexpr (EPI == EPI_HEAD) v[r] *= (co < a.Cout ? a.head_w[cc] : 0.f);
+                    }
+                    if constexpr (EPI == EPI_HEAD) {
+                        hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = co0 + m * 16 + r;
+                            float w_ = v[r];
+                            if (a.norm_out) w_ = w_ * out_scale + out_shift;
+                            if (co < a.Cout) a.out[(size_t)co * vol_out + pix_out] = w_;
                         }
                     }
                 }
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
     }  // co-group loop
 
-    if (a.head_w) {
+    if constexpr (EPI == EPI_HEAD) {
         // fused 1x1 head: reduce over the four 16-lane groups (they hold different co of the same pixel)
         const size_t plane_o = (size_t)a.Hout * a.Wout;
 #pragma unroll

@@ -24,9 +24,9 @@ static std::vector<ConvKernelInfo>& registry() {
     return r;
 }
 void register_conv(const ConvKernelInfo& info) { registry().push_back(info); }
-const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1) {
+const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1, int epi) {
     for (const auto& k : registry())
-        if (k.dims == dims && k.K == K && k.D == D && k.MT == MT && k.cin1 == (cin1 ? 1 : 0)) return &k;
+        if (k.dims == dims && k.K == K && k.D == D && k.MT == MT && k.cin1 == (cin1 ? 1 : 0) && k.epi == epi) return &k;
     return nullptr;
 }
 }  // namespace tpz
@@ -215,10 +215,15 @@ static const int MT_CHOICES[] = {16, 32, 48, 64, 96, 128};
 static const ConvKernelInfo* choose_kernel(const tpz_layer& L, bool* cin1_out) {
     if (L.cout == 1 && !L.head) return nullptr;      // M = 1: nothing for the matrix cores to do
     const bool cin1 = (L.cin == 1 && L.src2 < 0);
+    // epilogue variant the layer needs (conv_mfma.h EPI_*)
+    int epi = EPI_PLAIN;
+    if (L.head) epi = EPI_HEAD;
+    else if (L.res >= 0) epi = L.post_scale_off >= 0 ? EPI_RES_POST : EPI_RES;
+    if ((L.head && (L.res >= 0 || L.post_scale_off >= 0)) || (L.res < 0 && L.post_scale_off >= 0)) return nullptr;
     const ConvKernelInfo* best = nullptr;
     int best_padded = 1 << 30;
     for (int mt : MT_CHOICES) {
-        const ConvKernelInfo* k = find_conv(L.dims, L.k, L.dil, mt, cin1);
+        const ConvKernelInfo* k = find_conv(L.dims, L.k, L.dil, mt, cin1, epi);
         if (!k) continue;
         const int padded = (L.cout + mt - 1) / mt * mt;
         if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
