@@ -109,3 +109,29 @@ def test_full_size_4096_default_patching_vs_oracle_patch(gpu_ctx):
         ref = oden.denoise_whole('unet', oden.to_torch_sd(sd), torch.from_numpy(x[si:ei, sj:ej].copy()))
         ref = ref[i - si:i - si + 1024, j - sj:j - sj + 1024]
         assert _err(y[i:i + 1024, j:j + 1024], ref, 2.0) <= ATOL, (i, j)
+
+
+def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):
+    """BASELINE config 5: 512x512x256 tomogram, unet-3d architecture (nf 48, base 7; seeded), 96/48 tiles
+    (108 tiles of 192^3).  Two tiles are recomputed with the oracle from the reference's tiling rule
+    (datasets.py:426-468 zero-filled crop, global (x-mu)/std, per-tile _denoise, *std+mu)."""
+    import torch
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)
+    tomo = np.random.RandomState(2000).randn(256, 512, 512).astype(np.float32)
+    d = Denoise3D(DenoiseNet('unet-3d', sd))
+    y = d.denoise(tomo, 96, 48, verbose=False)
+    assert y.shape == tomo.shape and np.isfinite(y).all()
+    mu, std = tomo.mean(), tomo.std()
+    tsd = oden.to_torch_sd(sd)
+    for (i, j, k) in ((0, 0, 0), (192, 480, 288)):
+        x = np.zeros((192, 192, 192), dtype=np.float32)
+        si, ei = max(0, i - 48), min(256, i + 144)
+        sj, ej = max(0, j - 48), min(512, j + 144)
+        sk, ek = max(0, k - 48), min(512, k + 144)
+        x[48 - i + si:48 - i + ei, 48 - j + sj:48 - j + ej, 48 - k + sk:48 - k + ek] = tomo[si:ei, sj:ej, sk:ek]
+        out = oden.denoise_whole('unet-3d', tsd, (torch.from_numpy(x) - mu) / std) * std + mu
+        pz, py, px = min(96, 256 - i), min(96, 512 - j), min(96, 512 - k)
+        ref = out[48:48 + pz, 48:48 + py, 48:48 + px]
+        assert _err(y[i:i + pz, j:j + py, k:k + px], ref) <= ATOL, (i, j, k)
