@@ -57,6 +57,8 @@ int bench(const char* name, int cin, int cout, int H) {
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
     RUN(16, "static priority on odd wave slots");
+    { ConvArgs b = a; b.xcd_swizzle = 1; float ms = run<C, 0>(b, grid, 2);
+      printf("  %-44s %8.3f ms  %6.1f TF/s\n", "XCD-aware tile order", ms, tf / (ms * 1e-3)); }
     {
         ConvArgs b = a;
         b.stagger_first = 512;

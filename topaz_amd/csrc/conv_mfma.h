@@ -57,6 +57,7 @@ struct ConvArgs {
     int n_chunks;             // channel chunks of NCH channels
     float slope;              // activation: v > 0 ? v : v*slope   (1.0 = identity, 0.0 = ReLU)
     int tiles_x, tiles_y, tiles_z;
+    int xcd_swizzle;          // 1: remap workgroup ids so that each XCD owns a contiguous run of tiles
     int stagger_first;        // workgroups with a linear id below this belong to the first generation
     int stagger_sleeps;       // s_sleep(127) repeats for the odd wave slot of the first generation (0 = off)
 };
@@ -177,11 +178,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
 
     // ---- tile coordinates. y (and z) tiles are polyphase: row i of the tile is y0 + i*D.
-    const int ty = blockIdx.y % a.tiles_y;
-    const int tz = blockIdx.y / a.tiles_y;
+    // XCD-aware order: consecutive workgroup ids are dispatched round-robin over the 8 XCDs (each with its
+    // own L2), so the (x, y) tile is taken from a remapped id that gives every XCD a contiguous run of
+    // tiles -- x-neighbours, which share 24 of 56 halo columns, then hit the same L2.  Bijective for any
+    // grid size (cdna_hip_programming.md 5.5 T1).  Speed only; no correctness dependence.
+    int bx = blockIdx.x, byz = blockIdx.y;
+    if (a.xcd_swizzle) {
+        const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        bx = (int)(wgid % gridDim.x);
+        byz = (int)(wgid / gridDim.x);
+    }
+    const int ty = byz % a.tiles_y;
+    const int tz = byz / a.tiles_y;
     const int y0 = (ty / D) * (C::TH * D) + (ty % D);
     const int z0 = (C::DIMS == 3) ? (tz / D) * (C::TD * D) + (tz % D) : 0;
-    const int x0 = blockIdx.x * C::TW;
+    const int x0 = bx * C::TW;
     // The LDS tile starts PADA = roundup4(pad) pixels left of x0, so every 4-float LDS granule maps to a
     // 16-byte aligned global run when the row pitch is a multiple of 4 floats; B reads shift by PADA - pad.
     const int pada = (a.pad + 3) & ~3;

@@ -355,6 +355,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
             return fail(ctx, "fused concat needs the first source's channels (%d) to be a multiple of %d", s1.C, ki.NCH);
         a.n_chunks = rt.n_chunks;
         a.cog_inner = rt.cog_inner;
+        a.xcd_swizzle = 1;
         {   // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
             const long long wgs = (long long)((dst.W + ki.TW - 1) / ki.TW) * ((dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D);
             if (wgs >= 4096) {
