@@ -135,3 +135,20 @@ def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):
         pz, py, px = min(96, 256 - i), min(96, 512 - j), min(96, 512 - k)
         ref = out[48:48 + pz, 48:48 + py, 48:48 + px]
         assert _err(y[i:i + pz, j:j + py, k:k + px], ref) <= ATOL, (i, j, k)
+
+
+def test_edge_cases(gpu_ctx):
+    from topaz_amd._lib import TopazHipError
+    from topaz_amd.denoise import Denoise
+    d = Denoise('unet-v0.2.1')
+    sd = {k: v.numpy() for k, v in d.model.state_dict().items()}
+    # the smallest image the 5-level U-Net accepts (32 -> 16 -> 8 -> 4 -> 2 -> 1) and a ragged one
+    for shape in ((32, 32), (33, 47)):
+        x = np.random.RandomState(shape[1]).randn(*shape).astype(np.float32)
+        assert _err(d.denoise(x, -1), oden.denoise('unet', sd, x, -1)) <= ATOL
+    # too small to pool five times: the reference dies inside max_pool2d; here a clear error
+    with pytest.raises(TopazHipError, match='too small'):
+        d.denoise(np.random.randn(20, 40).astype(np.float32), -1)
+    # constant image: std = 0 -> the reference returns NaN everywhere; so do we
+    y = d.denoise(np.full((40, 40), 3.0, dtype=np.float32), -1)
+    assert np.isnan(y).all()

@@ -125,3 +125,28 @@ def test_full_size_4096_windows_vs_oracle(gpu_ctx):
         # inside the image are only valid `p` pixels away from the cut
         ref_win = ref[y0 - ys:y0 - ys + h, x0 - xs:x0 - xs + w]
         assert np.abs(y[y0:y0 + h, x0:x0 + w] - ref_win).max() <= ATOL, (y0, x0)
+
+
+def test_edge_tiny_and_ragged_images(gpu_ctx):
+    """images smaller than the 71-pixel receptive field / a single tile, and ragged (odd, prime) sizes"""
+    from topaz_amd.model.factory import load_model
+    m = load_model('resnet8_u32')
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    for shape in ((1, 1), (7, 5), (20, 33), (71, 71), (101, 257)):
+        x = np.random.RandomState(sum(shape)).randn(*shape).astype(np.float32)
+        y = _score(m, x)
+        assert y.shape == shape
+        assert np.abs(y - oscoring.score('resnet8', sd, x)).max() <= ATOL, shape
+
+
+def test_batched_scoring_matches_single(gpu_ctx):
+    """topaz.predict.score semantics: a batch is scored image by image (predict.py:18-28)"""
+    from topaz_amd.model.factory import load_model
+    from topaz_amd.predict import score
+    m = load_model('resnet16_u32')
+    m.eval(); m.fill(); m.cuda()
+    imgs = [np.random.RandomState(s).randn(64, 80).astype(np.float32) for s in (1, 2, 3)]
+    out = score(m, imgs, batch_size=2)
+    assert len(out) == 3
+    for x, y in zip(imgs, out):
+        assert np.array_equal(y, m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy())

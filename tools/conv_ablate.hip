@@ -83,5 +83,9 @@ int main() {
     if (bench<ConvCfg<5, 4, 128, 1, 8, 32, 1, 1, false, 2>>("K5 D4 MT128 RPS1", 128, 256, 2064)) return 1;
     if (bench<ConvCfg<3, 8, 128, 1, 8, 32, 1, 3, false, 2>>("K3 D8 MT128", 128, 128, 2064)) return 1;
     if (bench<ConvCfg<3, 2, 64, 1, 16, 32, 1, 3, false, 2>>("K3 D2 MT64", 64, 64, 2052)) return 1;
+    if (bench<ConvCfg<5, 1, 64, 1, 16, 32, 1, 1, false, 2>>("K5 D1 MT64 (x4 DMA)", 96, 64, 2028)) return 1;
+    if (bench<ConvCfg<5, 1, 64, 1, 16, 32, 1, 1, false, 2>>("K5 D1 MT64 (x1 DMA: width % 4 != 0)", 96, 64, 2030)) return 1;
+    if (bench<ConvCfg<3, 1, 96, 1, 8, 32, 1, 3, false, 2>>("K3 D1 MT96 (x4)", 144, 96, 1016)) return 1;
+    if (bench<ConvCfg<3, 1, 96, 1, 8, 32, 1, 3, false, 2>>("K3 D1 MT96 (x1)", 144, 96, 1018)) return 1;
     return 0;
 }
