@@ -43,7 +43,6 @@ struct ConvArgs {
     const float* zeros;       // >= 16 bytes of zeros in global memory (source of padded / OOB elements)
     const float* nrm;         // device float[4] {in_scale, in_shift, out_scale, out_shift} or nullptr
     float head_b;
-    int norm_src;             // (direct kernel only) bit0: x' = x*in_scale+in_shift on in-bounds pixels of `in`
     int norm_out;             // y' = y*out_scale+out_shift applied last
     int Cin, Cin1;            // Cin1 = channels taken from `in` (== Cin when no concat)
     int Din, Hin, Win;        // logical input geometry (== geometry of in2; `in` is nearest-upsampled to it)

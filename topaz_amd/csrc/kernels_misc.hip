@@ -19,9 +19,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, cons
     const int oz = blockIdx.z % a.Dout;
     const int co = blockIdx.z / a.Dout;
     if (ox >= a.Wout || oy >= a.Hout) return;
-    float in_scale = 1.f, in_shift = 0.f, out_scale = 1.f, out_shift = 0.f;
-    if (a.nrm) { in_scale = a.nrm[0]; in_shift = a.nrm[1]; out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
-    const bool norm1 = (a.norm_src & 1) != 0;
+    float out_scale = 1.f, out_shift = 0.f;
+    if (a.nrm && a.norm_out) { out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
     float acc = 0.f;
     const float* wc = w + (size_t)co * a.Cin * KZ * K * K;
     for (int ci = 0; ci < a.Cin; ++ci) {
@@ -37,9 +36,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, cons
                 for (int kx = 0; kx < K; ++kx) {
                     const int gx = ox - a.pad + kx * dil;
                     if ((unsigned)gx < (unsigned)a.Win) {
-                        float v = row[gx];
-                        if (norm1) v = v * in_scale + in_shift;
-                        acc = fmaf(wr[kx], v, acc);
+                        acc = fmaf(wr[kx], row[gx], acc);
                     }
                 }
             }
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
 }
 
 hipError_t launch_conv_direct(const ConvArgs& a, const float* d_w, int K, int KZ, int dil, hipStream_t s) {
-    if (KZ == 1 && dil == 1 && a.Cout == 1 && (K == 3 || K == 5) && (a.norm_src & 1) == 0) {
+    if (KZ == 1 && dil == 1 && a.Cout == 1 && (K == 3 || K == 5)) {
         dim3 grid((a.Wout + 63) / 64, (a.Hout + 15) / 16, 1);
         if (K == 3) hipLaunchKernelGGL(conv_cout1_tiled_kernel<3>, grid, dim3(256), 0, s, a, d_w);
         else hipLaunchKernelGGL(conv_cout1_tiled_kernel<5>, grid, dim3(256), 0, s, a, d_w);

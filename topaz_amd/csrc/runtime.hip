@@ -212,7 +212,7 @@ static int upload(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** 
 static const int MT_CHOICES[] = {16, 32, 48, 64, 96, 128};
 
 // choose the MFMA instantiation for a conv layer; returns nullptr when the direct kernel must be used
-static const ConvKernelInfo* choose_kernel(const tpz_layer& L, bool* cin1_out) {
+static const ConvKernelInfo* choose_kernel(const tpz_layer& L) {
     if (L.cout == 1 && !L.head) return nullptr;      // M = 1: nothing for the matrix cores to do
     const bool cin1 = (L.cin == 1 && L.src2 < 0);
     // epilogue variant the layer needs (conv_mfma.h EPI_*)
@@ -231,7 +231,6 @@ static const ConvKernelInfo* choose_kernel(const tpz_layer& L, bool* cin1_out) {
             best_padded = padded;
         }
     }
-    *cin1_out = cin1;
     return best;
 }
 
@@ -282,8 +281,7 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
     const size_t wn = (size_t)L.cout * L.cin * taps;
     if (L.w_off < 0 || (size_t)L.w_off + wn > n_floats) return fail(ctx, "conv: weight offset out of range");
     const float* w = blob + L.w_off;
-    bool cin1 = false;
-    rt.ki = choose_kernel(L, &cin1);
+    rt.ki = choose_kernel(L);
     if (rt.ki) {
         const ConvKernelInfo& ki = *rt.ki;
         rt.n_cog = (L.cout + ki.MT - 1) / ki.MT;
@@ -317,7 +315,7 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
 // executor
 // ------------------------------------------------------------------------------------------------
 static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* s2, const Slot* sres, Slot& dst,
-                    const float* d_nrm, int norm_src, int norm_out) {
+                    const float* d_nrm, int norm_out) {
     const tpz_layer& L = rt.L;
     ConvArgs a;
     memset(&a, 0, sizeof a);
@@ -332,7 +330,6 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.head_b = rt.head_b;
     a.nrm = d_nrm;
     a.zeros = ctx->d_zeros;
-    a.norm_src = d_nrm ? norm_src : 0;
     a.norm_out = d_nrm ? norm_out : 0;
     a.Cin = L.cin;
     a.Cin1 = s1.C;
@@ -419,8 +416,8 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
                 rc = fail(ctx, "layer %d: residual geometry mismatch", i);
                 break;
             }
-            const int norm_src = 0;      // slot 0 arrives already normalised (denoise_region)
-            rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, norm_src, (d_nrm && i == nl - 1) ? 1 : 0);
+            // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
+            rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
             const int Do = L.dims == 3 ? s1.D / 2 : 1, Ho = s1.H / 2, Wo = s1.W / 2;
@@ -603,7 +600,7 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
 // ---- denoising ---------------------------------------------------------------------------------
 // Denoise._denoise on a (strided) region: mean / unbiased std -> normalise -> network -> un-normalise.
 // mode 1: plain; mode 2: the un-normalisation also applies the volume's std*y+mu with g = {mu, std}.
-static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int dims, int mode = 1,
+static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int mode = 1,
                           const float* d_g = nullptr) {
     tpz_ctx* ctx = m->ctx;
     float* nrm = next_nrm(ctx);
@@ -622,7 +619,6 @@ static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, in
     if (e != hipSuccess) { pool_release(ctx, xn); return fail(ctx, "affine_dev failed: %s", hipGetErrorString(e)); }
     std::vector<Slot> slots(m->n_slots);
     set_dense(slots[0], xn, 1, view.D, view.H, view.W);
-    (void)dims;
     const int rc = run_program(m, slots, d_out_dense, nrm);
     pool_release(ctx, xn);
     return rc;
@@ -640,7 +636,7 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
     if (!use_patch) {
         Slot v;
         set_dense(v, const_cast<float*>(d_in), 1, 1, H, W);
-        return denoise_region(m, v, d_out, 2);
+        return denoise_region(m, v, d_out);
     }
     for (int i = 0; i < H; i += patch)
         for (int j = 0; j < W; j += patch) {
@@ -654,7 +650,7 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
             v.cs = v.ps;
             float* tmp = (float*)pool_alloc(ctx, (size_t)ph * pw * sizeof(float));
             if (!tmp) return fail(ctx, "out of device memory");
-            int rc = denoise_region(m, v, tmp, 2);
+            int rc = denoise_region(m, v, tmp);
             if (rc == 0) {
                 const int oi = i - si, oj = j - sj;
                 const int ch = std::min(patch, std::min(H - i, ph - oi)), cw = std::min(patch, std::min(W - j, pw - oj));
@@ -677,7 +673,7 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
     if (patch < 1) {
         Slot v;
         set_dense(v, const_cast<float*>(d_in), 1, D, H, W);
-        return denoise_region(m, v, d_out, 3);
+        return denoise_region(m, v, d_out);
     }
     // global mean / population std (numpy, denoise.py:343)
     float* g = next_nrm(ctx);
@@ -697,7 +693,7 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
                 if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
                 Slot tv;
                 set_dense(tv, tile, 1, d, d, d);
-                rc = denoise_region(m, tv, tout, 3, 2, g);
+                rc = denoise_region(m, tv, tout, 2, g);
                 if (rc) break;
                 const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
                 prof_begin(ctx, 2, 0);

@@ -19,7 +19,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('TOPAZ_AMD_FORCE_DIST') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -64,11 +64,10 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
     the root over its own xGMI link.  Returns on dst a dict id -> (scores, coords) (CPU tensors), on
     the other ranks None.
     """
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
     d = coords[0].shape[1] if len(coords) else 2
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return {int(i): (s.cpu(), c.cpu()) for i, s, c in zip(image_ids, scores, coords)}
+    world, rank = dist.get_world_size(), dist.get_rank()      # (a 1-rank group takes the collective path too)
     n_img = len(image_ids)
     n_rows = int(sum(int(s.numel()) for s in scores))
     meta = torch.tensor([n_img, n_rows, d], dtype=torch.int64, device=device)
