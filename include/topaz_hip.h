@@ -138,6 +138,9 @@ int tpz_conv(tpz_ctx* ctx, int dims, const float* d_in, int cin1, int D1, int H1
              int pad, float slope, const float* d_res, int res_crop, const float* h_post_scale,
              const float* h_post_shift, const float* h_head_w, float head_b, float* d_out);
 int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H, int W, float* d_out);
+/* d_out[cols][rows] = d_in[rows][cols]; used by the truncated-DFT downsample (topaz/utils/image.py:38-61),
+ * which runs as two GEMMs (tpz_conv with k = 1) around a transpose -- see topaz_amd/utils/image.py */
+int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float* d_out);
 
 /* ---- introspection / measurement --------------------------------------------------------- */
 /* time (ms, HIP events on the ctx stream) and launch count of the kernels of one class since

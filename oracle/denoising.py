@@ -209,3 +209,15 @@ def synthetic_unet_sd(seed: int, nf: int = 48, base_width: int = 11, top_width: 
     conv('dec1.2', 32, 64, top_width)
     conv('dec1.4', 1, 32, top_width)
     return sd
+
+
+def downsample(x: np.ndarray, factor=1, shape=None) -> np.ndarray:
+    """truncated-DFT downsample, restating topaz/utils/image.py:38-61: rfft2, keep the m x (n//2+1) block of
+    low frequencies (rows 0..m//2-1 and the last ceil(m/2)), scale by (m*n)/(M*N), irfft2."""
+    if shape is None:
+        shape = (int(x.shape[-2] / factor), int(x.shape[-1] / factor))
+    m, n = shape
+    F = np.fft.rfft2(x)
+    F = np.concatenate([F[..., 0:m // 2, 0:n // 2 + 1], F[..., -m // 2:, 0:n // 2 + 1]], axis=0)
+    F = F * ((n * m) / (x.shape[-2] * x.shape[-1]))
+    return np.fft.irfft2(F, s=shape).astype(x.dtype)

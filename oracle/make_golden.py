@@ -284,8 +284,21 @@ def cli():
         print('cli/' + fn, os.path.getsize(os.path.join(cli_dir, fn)))
 
 
+def downsample():
+    """truncated-DFT downsample (utils/image.py:38-61), the step before the path in `topaz preprocess`"""
+    from topaz.utils.image import downsample as ref_downsample
+    out = {}
+    for name, (h, w), factor in (('even_f2', (200, 260), 2), ('even_f4', (256, 320), 4), ('odd_f3', (201, 263), 3),
+                                 ('odd_f8', (333, 250), 8)):
+        x = image(81 + h, h, w) * 2 + 1
+        out[name + ':x'] = x
+        out[name + ':factor'] = np.asarray(factor)
+        out[name + ':y'] = ref_downsample(x, factor)
+    save('downsample_cases', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d', 'cli']
+    which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d', 'cli', 'downsample']
     torch.set_num_threads(8)
     for w in which:
         globals()[w]()

@@ -191,3 +191,32 @@ def test_maxpool3d(gpu_ctx):
     from topaz_amd import runtime as rt
     x = torch.randn(7, 9, 11, 13)
     assert torch.equal(rt.maxpool2(x).cpu(), F.max_pool3d(x[None], 2)[0])
+
+
+def test_transpose(gpu_ctx):
+    from topaz_amd import runtime as rt
+    for shape in ((1, 1), (63, 65), (200, 130), (1024, 96)):
+        x = torch.randn(*shape)
+        assert torch.equal(rt.transpose(x).cpu(), x.t().contiguous())
+
+
+def test_downsample_vs_reference_golden(gpu_ctx):
+    """truncated-DFT downsample as two fp32-MFMA GEMMs + transposes vs numpy's FFT path in the reference"""
+    from conftest import load_golden
+    from topaz_amd.utils.image import downsample
+    z = load_golden('downsample_cases')
+    for name in sorted({k.split(':')[0] for k in z.files if ':' in k}):
+        y = downsample(z[name + ':x'], int(z[name + ':factor']))
+        ref = z[name + ':y']
+        assert y.shape == ref.shape and y.dtype == ref.dtype
+        assert np.abs(y - ref).max() <= 1e-4, (name, np.abs(y - ref).max())
+
+
+def test_downsample_4096(gpu_ctx):
+    """BASELINE-size image: 4096^2 -> 512^2, against the oracle restatement (numpy FFT)"""
+    from oracle.denoising import downsample as oracle_downsample
+    from topaz_amd.utils.image import downsample
+    x = np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)
+    y = downsample(x, 8)
+    assert y.shape == (512, 512)
+    assert np.abs(y - oracle_downsample(x, 8)).max() <= 1e-4

@@ -129,3 +129,11 @@ def test_denoise3d_seeded():
     sd = golden_sd(z)
     np.testing.assert_allclose(denoising.denoise3d(sd, z['tomo'], 32, 16), z['p32_16'], atol=2e-5, rtol=0)
     np.testing.assert_allclose(denoising.denoise3d(sd, z['small'], -1, 0), z['small_whole'], atol=2e-5, rtol=0)
+
+
+def test_downsample_golden():
+    z = load_golden('downsample_cases')
+    for name in sorted({k.split(':')[0] for k in z.files if ':' in k}):
+        y = denoising.downsample(z[name + ':x'], int(z[name + ':factor']))
+        assert y.shape == z[name + ':y'].shape and y.dtype == z[name + ':y'].dtype
+        np.testing.assert_allclose(y, z[name + ':y'], atol=1e-6, rtol=0)

@@ -304,6 +304,31 @@ hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* d
 }
 
 // ------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c] through a padded 64x64 LDS tile (both sides coalesced)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int Cc) {
+    __shared__ float t[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        const int r = r0 + k, c = c0 + tx;
+        t[k][tx] = (r < R && c < Cc) ? in[(size_t)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < Cc && r < R) out[(size_t)c * R + r] = t[tx][k];
+    }
+}
+
+hipError_t launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t s) {
+    if (R <= 0 || Cc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, s, in, out, R, Cc);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // PatchDataset.__getitem__ (denoising/datasets.py:426-468) fused with the global normalisation
 // (denoise.py:355): tile[d][d][d] = ((inside ? tomo : 0) - mu)/std, with g = {mu, std} on device.
 // ------------------------------------------------------------------------------------------

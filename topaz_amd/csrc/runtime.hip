@@ -790,6 +790,16 @@ int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H,
     return 0;
 }
 
+int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float* d_out) {
+    if (!ctx || !d_in || !d_out) return fail(ctx, "tpz_transpose_2d: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    prof_begin(ctx, 2, 0);
+    hipError_t e = launch_transpose(d_in, d_out, rows, cols, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
 int tpz_filter_2d(tpz_ctx* ctx, const float* d_in, int H, int W, const float* h_w, int k, float bias, float* d_out) {
     if (!ctx || !d_in || !h_w || !d_out || k < 1 || (k & 1) == 0) return fail(ctx, "tpz_filter_2d: bad arguments");
     return tpz_conv(ctx, 2, d_in, 1, 1, H, W, nullptr, 1, 1, H, W, h_w, &bias, 1, k, 1, k / 2, 1.0f, nullptr, 0, nullptr,

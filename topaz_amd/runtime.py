@@ -341,3 +341,13 @@ def nms(score: torch.Tensor, r: int, threshold: float, scale: float = 1.0, ctx: 
             continue
         check(rc, ctx.handle)
         return out[:n.value], coords[:n.value]
+
+
+def transpose(x: torch.Tensor, ctx: Optional[Context] = None) -> torch.Tensor:
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    R, Cc = x.shape
+    y = torch.empty((Cc, R), dtype=torch.float32, device=x.device)
+    check(ctx.lib.tpz_transpose_2d(ctx.handle, _ptr(x), R, Cc, _ptr(y)), ctx.handle)
+    return y
