@@ -117,7 +117,8 @@ def main():
     ap.add_argument('--patch-padding', type=int, default=500)
     ap.add_argument('--radius', type=int, default=14)
     ap.add_argument('--threshold', type=float, default=-6.0)
-    ap.add_argument('--cpu-sample', type=int, default=768)
+    ap.add_argument('--cpu-sample', type=int, default=1024)
+    ap.add_argument('--lanes', type=int, default=2, help='micrographs in flight per GPU (host threads / HIP streams)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -129,22 +130,62 @@ def main():
     from topaz_amd.runtime import get_context
     ctx = get_context(local_rank)
 
-    models = build_models(args.workload)
-    n_img = args.steps + args.warmup
     # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world)
+    n_img = args.steps + args.warmup * args.lanes
     imgs = [torch.from_numpy(np.random.RandomState(1000 + rank + i * world).randn(args.size, args.size)
                              .astype(np.float32)).to(dev) for i in range(n_img)]
 
-    for i in range(args.warmup):
-        run_step(models, imgs[i], args)
+    # Lanes: `--lanes L` host threads, each with its own tpz context (stream + workspace) and model copies,
+    # keep L micrographs in flight on the GPU; steps are dealt round-robin, exactly K steps are timed.
+    import threading
+    from topaz_amd import runtime as rt
+    start = threading.Barrier(args.lanes + 1)
+    ready = threading.Barrier(args.lanes + 1)
+    lane_models, results, errors = [None] * args.lanes, [[] for _ in range(args.lanes)], []
+
+    def lane_main(k):
+        try:
+            torch.cuda.set_device(local_rank)
+            rt.set_lane(k)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                lane_models[k] = build_models(args.workload)
+                for w in range(args.warmup):
+                    run_step(lane_models[k], imgs[args.steps + k * args.warmup + w], args)
+                torch.cuda.current_stream().synchronize()
+                ready.wait()
+                start.wait()
+                for i in range(k, args.steps, args.lanes):
+                    s, c = run_step(lane_models[k], imgs[i], args)
+                    if c is not None:
+                        results[k].append((rank + i * world, s, c))
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:          # surface worker failures in the main thread
+            errors.append(e)
+            for b in (ready, start):
+                try:
+                    b.abort()
+                except Exception:
+                    pass
+
+    threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(args.lanes)]
+    for t in threads:
+        t.start()
+    try:
+        ready.wait()
+    except threading.BrokenBarrierError:
+        pass
+    if errors:
+        raise errors[0]
     torch.cuda.synchronize(dev)
     parallel.barrier(dev)
     t0 = time.perf_counter()
-    ids, scs, cds = [], [], []
-    for i in range(args.warmup, n_img):
-        s, c = run_step(models, imgs[i], args)
-        if c is not None:
-            ids.append(rank + i * world); scs.append(s); cds.append(c)
+    start.wait()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    picks = sorted((r for lane in results for r in lane), key=lambda r: r[0])
+    ids, scs, cds = [p[0] for p in picks], [p[1] for p in picks], [p[2] for p in picks]
     if ids and world > 1:
         parallel.gather_pick_tables(ids, scs, cds, dev)       # the one RCCL exchange step
     torch.cuda.synchronize(dev)
@@ -152,6 +193,8 @@ def main():
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
     n_picks = int(sum(int(s.numel()) for s in scs)) if scs else 0
+    models = lane_models[0]
+    rt.set_lane(0)
 
     # ---- roofline of the dominant kernel class, measured live with HIP events on the kernel's stream
     ctx.prof_enable(True)
@@ -181,7 +224,7 @@ def main():
                 'workload': {'pipeline': 'denoise(unet b11/t5 nf48, -s 1024 -p 500) -> score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'extract': 'score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'denoise': 'denoise(unet b11/t5 nf48, -s 1024 -p 500)'}[args.workload],
-                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps,
+                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps, 'lanes_per_gpu': args.lanes,
                 'parallelism': f'one micrograph per rank x{world}; RCCL gather of pick tables',
                 'picks_per_image': n_picks / max(1, len(scs)) if scs else None,
             },

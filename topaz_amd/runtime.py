@@ -14,7 +14,22 @@ import torch
 from . import _lib
 from ._lib import TpzLayer, check, load_library
 
+import threading
+
 _contexts = {}
+_tls = threading.local()
+
+
+def set_lane(lane: int) -> None:
+    """Lanes are independent execution contexts on one GPU (own tpz_ctx: HIP stream, workspace pool,
+    scratch).  A host thread that calls set_lane(k) gets lane k's context from get_context(); with one
+    lane per thread two micrographs can be in flight and one's under-filled launches and host syncs
+    (NMS counter reads) overlap the other's convolutions."""
+    _tls.lane = int(lane)
+
+
+def get_lane() -> int:
+    return getattr(_tls, 'lane', 0)
 
 
 class Context:
@@ -59,10 +74,11 @@ class Context:
 def get_context(device: Optional[int] = None) -> Context:
     if device is None or device < 0:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    ctx = _contexts.get(device)
+    key = (device, get_lane())
+    ctx = _contexts.get(key)
     if ctx is None:
         ctx = Context(device)
-        _contexts[device] = ctx
+        _contexts[key] = ctx
     ctx.bind_current_stream()
     return ctx
 
