@@ -109,7 +109,7 @@ def cpu_baseline(models, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='pipeline', choices=['pipeline', 'extract', 'denoise'])
     ap.add_argument('--size', type=int, default=4096)

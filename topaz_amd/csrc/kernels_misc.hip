@@ -49,51 +49,57 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, cons
     a.out[((size_t)co * a.Dout + oz) * a.Hout * a.Wout + (size_t)oy * a.Wout + ox] = v;
 }
 
-// LDS-tiled variant for the U-Net output convs (Cin -> 1, k = 3 or 5, dilation 1): a workgroup computes a
-// 16 x 64 pixel tile, each thread a strip of 4 pixels; per input channel and tap row it reads 4+K-1
-// neighbouring values with two ds_read_b128 and issues 4*K FMAs with scalar (SGPR) weights.
-// HBM-bound: reads Cin floats and writes one per pixel (AI = 2*K*K*Cin / (4*(Cin+1)) ~ 12 flop/B).
-template <int K>
+// LDS-tiled variant for the U-Net output convs (Cin -> 1, k = 3 or 5, dilation 1; 2-D and 3-D): a workgroup
+// computes a TD x TH x 64 pixel tile (1 x 16 x 64 in 2-D, 4 x 4 x 64 in 3-D), each thread a strip of 4 pixels;
+// per input channel and tap row it reads 4+K-1 neighbouring values with two ds_read_b128 and issues 4*K FMAs
+// with scalar (SGPR) weights.  HBM-bound: reads Cin floats and writes one per pixel (AI ~ 12 flop/B in 2-D).
+template <int K, int DIMS>
 __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a, const float* __restrict__ w) {
-    constexpr int TH = 16, TW = 64, CC = 8;
-    constexpr int ITH = TH + K - 1, RS = (TW + K - 1 + 3) / 4 * 4 + 4, CS = ITH * RS;
+    constexpr int TD = DIMS == 3 ? 4 : 1, TH = DIMS == 3 ? 4 : 16, TW = 64;
+    constexpr int KZ = DIMS == 3 ? K : 1;
+    constexpr int CC = DIMS == 3 ? 4 : 8;
+    constexpr int ITD = TD + KZ - 1, ITH = TH + K - 1, RS = (TW + K - 1 + 3) / 4 * 4 + 4, PS = ITH * RS, CS = ITD * PS;
     __shared__ __attribute__((aligned(16))) float tile[CC * CS];
     const int tid = threadIdx.x;
-    const int sx = tid & 15, sy = tid >> 4;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int sx = tid & 15, sy = (tid >> 4) % TH, sz = (tid >> 4) / TH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, z0 = blockIdx.z * TD;
     float out_scale = 1.f, out_shift = 0.f;
     if (a.nrm && a.norm_out) { out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < a.Cin; c0 += CC) {
         __syncthreads();
         for (int e = tid; e < CC * CS; e += 256) {
-            const int c = e / CS, rem = e - c * CS, r = rem / RS, x = rem - r * RS;
-            const int gy = y0 - a.pad + r, gx = x0 - a.pad + x, ci = c0 + c;
+            const int c = e / CS, rem = e - c * CS, zz = rem / PS, rem2 = rem - zz * PS, r = rem2 / RS, x = rem2 - r * RS;
+            const int gz = DIMS == 3 ? z0 - a.pad + zz : 0, gy = y0 - a.pad + r, gx = x0 - a.pad + x, ci = c0 + c;
             float v = 0.f;
-            if (ci < a.Cin && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win)
-                v = a.in[(long long)ci * a.cs1 + (long long)gy * a.pitch1 + gx];
+            if (ci < a.Cin && (unsigned)gz < (unsigned)a.Din && (unsigned)gy < (unsigned)a.Hin &&
+                (unsigned)gx < (unsigned)a.Win)
+                v = a.in[(long long)ci * a.cs1 + (long long)gz * a.ps1 + (long long)gy * a.pitch1 + gx];
             tile[e] = v;
         }
         __syncthreads();
         const int nc = min(CC, a.Cin - c0);
         for (int c = 0; c < nc; ++c) {
-            const float* wc = w + (size_t)(c0 + c) * K * K;      // uniform -> scalar loads
+            const float* wc = w + (size_t)(c0 + c) * KZ * K * K;      // uniform -> scalar loads
+#pragma unroll
+            for (int kz = 0; kz < KZ; ++kz)
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
-                const float4* row = reinterpret_cast<const float4*>(tile + c * CS + (sy + ky) * RS + sx * 4);
+                const float4* row =
+                    reinterpret_cast<const float4*>(tile + c * CS + (sz + kz) * PS + (sy + ky) * RS + sx * 4);
                 const float4 v0 = row[0], v1 = row[1];
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
-                    const float wv = wc[ky * K + kx];
+                    const float wv = wc[(kz * K + ky) * K + kx];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv, v[p + kx], acc[p]);
                 }
             }
         }
     }
-    const int oy = y0 + sy;
-    if (oy < a.Hout) {
+    const int oy = y0 + sy, oz = z0 + sz;
+    if (oy < a.Hout && oz < a.Dout) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int ox = x0 + sx * 4 + p;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
                 if (a.bias) v += a.bias[0];
                 v = v > 0.f ? v : v * a.slope;
                 if (a.norm_out) v = v * out_scale + out_shift;
-                a.out[(size_t)oy * a.Wout + ox] = v;
+                a.out[((size_t)oz * a.Hout + oy) * a.Wout + ox] = v;
             }
         }
     }
@@ -111,8 +117,13 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
 hipError_t launch_conv_direct(const ConvArgs& a, const float* d_w, int K, int KZ, int dil, hipStream_t s) {
     if (KZ == 1 && dil == 1 && a.Cout == 1 && (K == 3 || K == 5)) {
         dim3 grid((a.Wout + 63) / 64, (a.Hout + 15) / 16, 1);
-        if (K == 3) hipLaunchKernelGGL(conv_cout1_tiled_kernel<3>, grid, dim3(256), 0, s, a, d_w);
-        else hipLaunchKernelGGL(conv_cout1_tiled_kernel<5>, grid, dim3(256), 0, s, a, d_w);
+        if (K == 3) hipLaunchKernelGGL((conv_cout1_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a, d_w);
+        else hipLaunchKernelGGL((conv_cout1_tiled_kernel<5, 2>), grid, dim3(256), 0, s, a, d_w);
+        return hipGetLastError();
+    }
+    if (KZ == 3 && K == 3 && dil == 1 && a.Cout == 1 && (a.Dout + 3) / 4 <= 65535) {
+        dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, (a.Dout + 3) / 4);
+        hipLaunchKernelGGL((conv_cout1_tiled_kernel<3, 3>), grid, dim3(256), 0, s, a, d_w);
         return hipGetLastError();
     }
     dim3 grid((a.Wout + 63) / 64, (a.Hout + 3) / 4, a.Dout * a.Cout);
