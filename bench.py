@@ -197,13 +197,17 @@ def main():
     rt.set_lane(0)
 
     # ---- roofline of the dominant kernel class, measured live with HIP events on the kernel's stream
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    run_step(models, imgs[-1], args)
-    torch.cuda.synchronize(dev)
-    conv_ms, conv_n, conv_flops = ctx.prof_get(0)
-    other = {name: ctx.prof_get(k)[0] for k, name in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms'))}
-    ctx.prof_enable(False)
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):      # not the legacy default stream
+        ctx = get_context(local_rank)
+        run_step(models, imgs[-1], args)
+        torch.cuda.current_stream().synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        run_step(models, imgs[-1], args)
+        torch.cuda.current_stream().synchronize()
+        conv_ms, conv_n, conv_flops = ctx.prof_get(0)
+        other = {name: ctx.prof_get(k)[0] for k, name in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms'))}
+        ctx.prof_enable(False)
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
     if rank == 0:
