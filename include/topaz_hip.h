@@ -149,6 +149,9 @@ int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float*
 int tpz_prof_enable(tpz_ctx* ctx, int on);
 int tpz_prof_reset(tpz_ctx* ctx);
 int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops);
+/* the conv_mfma instantiation with the largest accumulated time since the last reset: total ms, launch count,
+ * algorithmic FLOP of those launches and its template parameters as text (matches the rocprofv3 kernel name) */
+int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len);
 
 #ifdef __cplusplus
 }

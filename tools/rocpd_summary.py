@@ -10,9 +10,12 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r'conv_mfma_kernel<tpz::ConvCfg<([^>]*)>', name)
+    m = re.search(r'conv_mfma_kernel<tpz::ConvCfg<([^>]*)>\s*,\s*(\d+)\s*,\s*(\d+)\s*>', name)
     if m:
-        return f'conv_mfma_kernel<K,D,MT,TD,TH,TW,KG,CIN1,DIMS={m.group(1).replace(" ", "")}>'
+        a = [x.strip() for x in m.group(1).split(',')]
+        keys = ['K', 'D', 'MT', 'TD', 'TH', 'TW', 'KG', 'RPS', 'CIN1', 'DIMS']
+        cfg = ','.join(f'{k}={v}' for k, v in zip(keys, a)).replace('CIN1=false', 'CIN1=0').replace('CIN1=true', 'CIN1=1')
+        return f'conv_mfma_kernel<{cfg},EPI={m.group(2)}>'
     name = re.sub(r'^void ', '', name)
     return name if len(name) < 110 else name[:107] + '...'
 

@@ -40,6 +40,11 @@ struct ProfRec {
     int cls;
     hipEvent_t e0, e1;
     double flops;
+    const void* key;      // identity of the kernel instantiation (ConvKernelInfo*), nullptr for the rest
+};
+struct ProfAcc {
+    double ms = 0, flops = 0;
+    long long n = 0;
 };
 
 struct tpz_ctx {
@@ -62,6 +67,7 @@ struct tpz_ctx {
     bool prof = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
+    std::vector<std::pair<const void*, ProfAcc>> per_kernel;   // conv_mfma instantiations
     double acc_ms[4] = {0, 0, 0, 0};
     long long acc_n[4] = {0, 0, 0, 0};
     double acc_flops[4] = {0, 0, 0, 0};
@@ -127,11 +133,12 @@ static float* next_nrm(tpz_ctx* ctx) {
 }
 
 // ---- profiling helpers
-static void prof_begin(tpz_ctx* ctx, int cls, double flops) {
+static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nullptr) {
     if (!ctx->prof) return;
     ProfRec r;
     r.cls = cls;
     r.flops = flops;
+    r.key = key;
     auto get = [&]() {
         hipEvent_t e;
         if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
@@ -156,6 +163,13 @@ static void prof_flush(tpz_ctx* ctx) {
         ctx->acc_ms[r.cls] += ms;
         ctx->acc_n[r.cls] += 1;
         ctx->acc_flops[r.cls] += r.flops;
+        if (r.key) {
+            ProfAcc* a = nullptr;
+            for (auto& kv : ctx->per_kernel)
+                if (kv.first == r.key) a = &kv.second;
+            if (!a) { ctx->per_kernel.push_back({r.key, ProfAcc()}); a = &ctx->per_kernel.back().second; }
+            a->ms += ms; a->flops += r.flops; a->n += 1;
+        }
         ctx->free_events.push_back(r.e0);
         ctx->free_events.push_back(r.e1);
     }
@@ -366,7 +380,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
         a.tiles_z = L.dims == 3 ? (dst.D + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
         if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
         dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, rt.n_cog / rt.cog_inner);
-        prof_begin(ctx, 0, flops);
+        prof_begin(ctx, 0, flops, &ki);
         hipError_t e = ki.launch(a, grid, ctx->stream);
         prof_end(ctx);
         HIPCHK(ctx, e);
@@ -921,6 +935,28 @@ int tpz_prof_reset(tpz_ctx* ctx) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     prof_flush(ctx);
     for (int i = 0; i < 4; ++i) { ctx->acc_ms[i] = 0; ctx->acc_n[i] = 0; ctx->acc_flops[i] = 0; }
+    ctx->per_kernel.clear();
+    return 0;
+}
+int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    prof_flush(ctx);
+    const void* best = nullptr;
+    ProfAcc acc;
+    for (auto& kv : ctx->per_kernel)
+        if (kv.second.ms > acc.ms) { best = kv.first; acc = kv.second; }
+    if (ms) *ms = acc.ms;
+    if (launches) *launches = acc.n;
+    if (flops) *flops = acc.flops;
+    if (name && name_len > 0) {
+        if (best) {
+            const ConvKernelInfo* k = (const ConvKernelInfo*)best;
+            snprintf(name, name_len, "conv_mfma_kernel<K=%d,D=%d,MT=%d,TD=%d,TH=%d,TW=%d,KG=%d,RPS=%d,CIN1=%d,DIMS=%d,EPI=%d>",
+                     k->K, k->D, k->MT, k->TD, k->TH, k->TW, k->KG, k->RPS, k->cin1, k->dims, k->epi);
+        } else {
+            name[0] = 0;
+        }
+    }
     return 0;
 }
 int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops) {

@@ -71,6 +71,17 @@ class Context:
         return ms.value, n.value, fl.value
 
 
+def _prof_get_dominant(self):
+    """(name, total ms, launches, algorithmic FLOP) of the conv_mfma instantiation with the most time"""
+    ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+    buf = C.create_string_buffer(256)
+    check(self.lib.tpz_prof_get_dominant(self.handle, C.byref(ms), C.byref(n), C.byref(fl), buf, 256), self.handle)
+    return buf.value.decode(), ms.value, n.value, fl.value
+
+
+Context.prof_get_dominant = _prof_get_dominant
+
+
 def get_context(device: Optional[int] = None) -> Context:
     if device is None or device < 0:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
