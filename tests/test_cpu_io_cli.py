@@ -95,7 +95,7 @@ def test_main_dispatch_and_at_file_expansion(tmp_path, capsys):
     with pytest.raises(SystemExit) as e:
         tmain.main(['@' + str(argfile)])
     assert e.value.code == 0
-    assert 'radius of the regions to extract' in capsys.readouterr().out
+    assert 'suppression radius in pixels' in capsys.readouterr().out
     with pytest.raises(SystemExit):
         tmain.main(['--version'])
 

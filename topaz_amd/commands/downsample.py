@@ -1,18 +1,13 @@
-"""`topaz downsample` -- topaz/commands/downsample.py:10-26 (truncated-DFT downsample, on the MI355X)."""
-import argparse
+"""`topaz downsample`: truncated-DFT reduction of one image on the MI355X (flag surface: _spec.DOWNSAMPLE,
+mirroring topaz/commands/downsample.py:10-26)."""
 
 name = 'downsample'
-help = 'downsample micrographs with truncated DFT'
+help = 'shrink an image by truncating its Fourier spectrum'
 
 
 def add_arguments(parser=None):
-    if parser is None:
-        parser = argparse.ArgumentParser()
-    parser.add_argument('file')
-    parser.add_argument('-s', '--scale', default=4, type=int, help='downsampling factor (default: 4)')
-    parser.add_argument('-o', '--output', help='output file')
-    parser.add_argument('-v', '--verbose', action='store_true', help='print info')
-    return parser
+    from ._spec import DOWNSAMPLE, build_parser
+    return build_parser(DOWNSAMPLE, help, parser)
 
 
 def main(args):

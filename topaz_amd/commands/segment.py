@@ -1,25 +1,16 @@
 """`topaz segment` -- topaz/commands/segment.py:16-56 + segment_images (model/utils.py:71-105)."""
-import argparse
 import os
 
 import numpy as np
 import torch
 
 name = 'segment'
-help = 'segment images using a trained region classifier'
+help = 'write per-pixel score maps of a trained classifier'
 
 
 def add_arguments(parser=None):
-    if parser is None:
-        parser = argparse.ArgumentParser(help)
-    parser.add_argument('paths', nargs='+', help='paths to image files for processing')
-    parser.add_argument('-m', '--model', default='resnet16', help='path to trained classifier. uses the pretrained resnet16 (2D) model by default.')
-    parser.add_argument('-o', '--destdir', help='output directory')
-    parser.add_argument('-d', '--device', default=0, type=int, help='which MI355X to use (default: 0)')
-    parser.add_argument('-j', '--num-threads', type=int, default=0, help='number of threads for pytorch, 0 uses pytorch defaults, <0 uses all cores (default: 0)')
-    parser.add_argument('-p', '--patch-size', type=int, default=None, help='size of patches to predict on, None will predict on the whole image (default: None)')
-    parser.add_argument('-v', '--verbose', action='store_true', help='verbose mode')
-    return parser
+    from ._spec import SEGMENT, build_parser
+    return build_parser(SEGMENT, help, parser)
 
 
 def segment_images(model, paths, output_dir, use_cuda, verbose, patch_size=None):

@@ -1,4 +1,9 @@
-"""Mirror of topaz/predict.py:7-35 (batches / score_stream / score)."""
+"""Batched scoring helpers with the call surface of topaz/predict.py:7-35 (`batches`, `score_stream`,
+`score`).  The HIP model scores the images of a batch one after another on the device, so batching only
+groups the host-to-device copies."""
+from __future__ import annotations
+
+from itertools import islice
 from typing import Iterable, Iterator, List
 
 import numpy as np
@@ -6,22 +11,21 @@ import torch
 
 
 def batches(X: Iterable[np.ndarray], batch_size: int = 1) -> Iterator[torch.Tensor]:
-    batch = []
-    for x in X:
-        batch.append(torch.from_numpy(np.ascontiguousarray(x)).float())
-        if len(batch) >= batch_size:
-            yield torch.stack(batch, 0)
-            batch = []
-    if len(batch) > 0:
-        yield torch.stack(batch, 0)
+    """stack consecutive images into fp32 tensors [<=batch_size, H, W]"""
+    it = iter(X)
+    while True:
+        group = [torch.as_tensor(np.array(x, dtype=np.float32)) for x in islice(it, max(1, batch_size))]
+        if not group:
+            return
+        yield torch.stack(group)
 
 
 def score_stream(model, images: Iterable[np.ndarray], use_cuda: bool = True, batch_size: int = 1) -> Iterator[np.ndarray]:
-    with torch.no_grad():
-        for x in batches(images, batch_size=batch_size):
-            logits = model(x.unsqueeze(1).cuda()).squeeze(1).cpu().numpy()
-            for i in range(len(logits)):
-                yield logits[i]
+    """yield one [H, W] logit map per image"""
+    for group in batches(images, batch_size):
+        with torch.no_grad():
+            logits = model(group[:, None].cuda())[:, 0]
+        yield from logits.cpu().numpy()
 
 
 def score(model, images: Iterable[np.ndarray], use_cuda: bool = True, batch_size: int = 1) -> List[np.ndarray]:
