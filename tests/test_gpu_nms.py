@@ -74,3 +74,57 @@ def test_large_map_properties(gpu_ctx):
     assert np.array_equal(c2, c) and np.array_equal(s2, s)
     so, co = onms.nms2d(x, r, thr)
     assert np.array_equal(c, co) and np.array_equal(s, so)
+
+
+def test_randomised_2d_sweep_vs_oracle(gpu_ctx):
+    """40 random configurations (shape, radius, threshold, tie density, plateaus, NaN / inf entries)"""
+    rs = np.random.RandomState(12345)
+    for trial in range(40):
+        H, W = int(rs.randint(1, 200)), int(rs.randint(1, 260))
+        r = int(rs.choice([0, 1, 2, 3, 5, 8, 14, 20]))
+        x = rs.randn(H, W).astype(np.float32)
+        kind = trial % 5
+        if kind == 1:
+            x = np.round(x * 2) / 2                        # heavy ties
+        elif kind == 2:
+            x[:] = 1.0                                     # one plateau: pure tie-break order
+        elif kind == 3 and H * W > 4:
+            idx = rs.randint(0, H * W, size=3)
+            x.ravel()[idx[0]] = np.inf
+            x.ravel()[idx[1]] = -np.inf
+        elif kind == 4:
+            x = (x * 1e-3).astype(np.float32)              # dense near-threshold values
+        thr = float(rs.choice([-np.inf, -1.0, 0.0, 0.5]))
+        so, co = onms.nms2d(x, r, thr)
+        s, c = _run(x, r, thr)
+        assert np.array_equal(c, co), (trial, H, W, r, thr)
+        assert np.array_equal(s, so), (trial, H, W, r, thr)
+
+
+def test_randomised_3d_sweep_vs_oracle(gpu_ctx):
+    rs = np.random.RandomState(54321)
+    for trial in range(15):
+        D, H, W = int(rs.randint(1, 20)), int(rs.randint(1, 30)), int(rs.randint(1, 40))
+        r, scale = int(rs.choice([0, 1, 2, 3])), float(rs.choice([1.0, 1.5, 2.0]))
+        v = rs.randn(D, H, W).astype(np.float32)
+        if trial % 3 == 1:
+            v = np.round(v)
+        thr = float(rs.choice([-np.inf, -0.5, 0.3]))
+        so, co = onms.nms3d(v, r, scale, thr)
+        s, c = _run(v, r, thr, scale)
+        assert np.array_equal(c, co) and np.array_equal(s, so), (trial, D, H, W, r, scale, thr)
+
+
+def test_nan_scores_sort_first(gpu_ctx):
+    """numpy's argsort puts NaN last, so reversed they are visited first; `NaN <= threshold` is False, so a
+    NaN pixel is a pick (and suppresses its neighbourhood) -- for either sign of the NaN payload"""
+    rs = np.random.RandomState(9)
+    x = rs.randn(40, 50).astype(np.float32)
+    x[5, 7] = np.nan
+    x[20, 30] = np.float32(np.nan) * -1
+    x.view(np.uint32)[30, 10] = 0xFFC00001              # negative quiet NaN with a payload
+    so, co = onms.nms2d(x, 4, 0.0)
+    s, c = _run(x, 4, 0.0)
+    assert np.array_equal(c, co)
+    assert np.array_equal(np.isnan(s), np.isnan(so)) and np.array_equal(s[~np.isnan(s)], so[~np.isnan(so)])
+    assert np.isnan(s[:3]).all() and set(map(tuple, c[:3].tolist())) == {(7, 5), (30, 20), (10, 30)}

@@ -28,6 +28,7 @@ enum : uint8_t { ST_NONE = 0, ST_UNDECIDED = 1, ST_SELECTED = 2, ST_SUPPRESSED =
 
 __device__ __forceinline__ uint32_t orderable(float f) {
     uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;   // any NaN sorts above everything (numpy puts NaN last)
     if (u == 0x80000000u) u = 0u;                    // -0.0 compares equal to +0.0
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
