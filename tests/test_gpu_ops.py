@@ -118,6 +118,32 @@ def test_conv2d_fused_upsample_concat(gpu_ctx, shape):
     _close(y, ref)
 
 
+@pytest.mark.parametrize('case', [
+    # c1, (h1, w1), c2, cout, k      -- skip source exactly 2x the first source: the phase path
+    (96, (19, 33), 1, 64, 5),        # U-Net dec1.0: 1-channel skip (CIN1 stem kernel adds in place)
+    (96, (40, 24), 48, 96, 3),       # dec2.0
+    (48, (9, 50), 24, 32, 3),
+    (32, (1, 1), 1, 64, 5),          # a single low-resolution pixel
+    (96, (64, 64), 1, 64, 3),
+])
+def test_conv2d_phase_upsample_concat(gpu_ctx, case):
+    """conv(cat(upsample2x(h), skip)) computed per output parity on the low-resolution source with pre-summed
+    taps (runtime.hip prepare_phases / run_conv_phases) against the literal interpolate + cat + conv."""
+    from topaz_amd import runtime as rt
+    c1, (h1, w1), c2, cout, k = case
+    H, W = 2 * h1, 2 * w1
+    g = torch.Generator().manual_seed(11)
+    h = torch.randn(c1, h1, w1, generator=g)
+    skip = torch.randn(c2, H, W, generator=g)
+    cin = c1 + c2
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    cat = torch.cat([F.interpolate(h[None], size=(H, W), mode='nearest'), skip[None]], 1)
+    ref = F.leaky_relu(F.conv2d(cat, w, b, padding=k // 2), 0.1)[0]
+    y = rt.conv(h, w.numpy(), b.numpy(), pad=k // 2, slope=0.1, x2=skip)
+    _close(y, ref)
+
+
 @pytest.mark.parametrize('shape', [(48, 37, 41), (3, 2, 2), (5, 64, 65)])
 def test_maxpool2(gpu_ctx, shape):
     from topaz_amd import runtime as rt
@@ -181,6 +207,29 @@ def test_conv3d_fused_upsample_concat(gpu_ctx, shape):
     cin = c1 + skip.shape[0]
     w = torch.randn(96, cin, 3, 3, 3, generator=g) / np.sqrt(cin * 27)
     b = torch.randn(96, generator=g)
+    cat = torch.cat([F.interpolate(h[None], size=(D, H, W), mode='nearest'), skip[None]], 1)
+    ref = F.leaky_relu(F.conv3d(cat, w, b, padding=1), 0.1)[0]
+    y = rt.conv(h, w.numpy(), b.numpy(), pad=1, slope=0.1, x2=skip)
+    _close(y, ref)
+
+
+@pytest.mark.parametrize('case', [
+    # c1, (d1, h1, w1), c2, cout
+    (96, (4, 5, 18), 1, 64),         # UDenoiseNet3D dec1.0
+    (96, (3, 6, 7), 48, 96),         # dec2.0
+    (16, (5, 4, 3), 8, 16),
+    (96, (1, 1, 1), 1, 64),
+])
+def test_conv3d_phase_upsample_concat(gpu_ctx, case):
+    from topaz_amd import runtime as rt
+    c1, (d1, h1, w1), c2, cout = case
+    D, H, W = 2 * d1, 2 * h1, 2 * w1
+    g = torch.Generator().manual_seed(12)
+    h = torch.randn(c1, d1, h1, w1, generator=g)
+    skip = torch.randn(c2, D, H, W, generator=g)
+    cin = c1 + c2
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(cin * 27)
+    b = torch.randn(cout, generator=g)
     cat = torch.cat([F.interpolate(h[None], size=(D, H, W), mode='nearest'), skip[None]], 1)
     ref = F.leaky_relu(F.conv3d(cat, w, b, padding=1), 0.1)[0]
     y = rt.conv(h, w.numpy(), b.numpy(), pad=1, slope=0.1, x2=skip)

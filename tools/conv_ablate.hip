@@ -46,7 +46,7 @@ int bench(const char* name, int cin, int cout, int H) {
     a.in = in; a.wpk = w; a.bias = bias; a.out = out; a.zeros = zeros;
     a.Cin = a.Cin1 = cin; a.Din = a.D1 = 1; a.Hin = a.H1 = H; a.Win = a.W1 = H;
     a.cs1 = (long long)H * H; a.ps1 = a.cs1; a.pitch1 = H;
-    a.cog_inner = 1; a.Cout = cout; a.Dout = 1; a.Hout = Ho; a.Wout = Ho; a.n_chunks = n_chunks; a.slope = 0.f;
+    a.cog_inner = 1; a.os = 1; a.Dfull = 1; a.Hfull = Ho; a.Wfull = Ho; a.Cout = cout; a.Dout = 1; a.Hout = Ho; a.Wout = Ho; a.n_chunks = n_chunks; a.slope = 0.f;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;
     a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
     a.tiles_z = 1;

@@ -51,7 +51,13 @@ struct ConvArgs {
     long long cs2, ps2; int pitch2;   // ... of `in2`
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int Cout, Dout, Hout, Wout;
-    int pad;                  // zero padding on every side
+    int pad;                  // zero padding on every side (direct kernels); the MFMA kernel uses the per-axis values
+    int pad_x, pad_y, pad_z;
+    // Output lattice: element (oz, oy, ox) of the launch is stored at (oz*os + ooz, oy*os + ooy, ox*os + oox) of
+    // a [Cout][Dfull][Hfull][Wfull] tensor (os = 1, offsets 0, full = out dims for an ordinary convolution;
+    // os = 2 for the phase launches of a conv over an exactly 2x nearest-upsampled source, see runtime.hip).
+    int os, ooz, ooy, oox;
+    int Dfull, Hfull, Wfull;
     int Dres, Hres, Wres, res_crop;
     int n_chunks;             // channel chunks of NCH channels
     float slope;              // activation: v > 0 ? v : v*slope   (1.0 = identity, 0.0 = ReLU)
@@ -196,9 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int x0 = bx * C::TW;
     // The LDS tile starts PADA = roundup4(pad) pixels left of x0, so every 4-float LDS granule maps to a
     // 16-byte aligned global run when the row pitch is a multiple of 4 floats; B reads shift by PADA - pad.
-    const int pada = (a.pad + 3) & ~3;
-    const int xshift = pada - a.pad;
-    const int ybase = y0 - a.pad, xbase = x0 - pada, zbase = (C::DIMS == 3) ? z0 - a.pad : 0;
+    const int pada = (a.pad_x + 3) & ~3;
+    const int xshift = pada - a.pad_x;
+    const int ybase = y0 - a.pad_y, xbase = x0 - pada, zbase = (C::DIMS == 3) ? z0 - a.pad_z : 0;
 
     // per-lane LDS read offsets (floats)
     const int b_lane = xshift + (C::CIN1 ? (l4 * D + l15) : (l4 * C::CS + l15)) +
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         // ---- epilogue: bias, residual, eval-BN affine, activation, (fused 1x1 head), store.
         // One predicate per 16-pixel fragment (not per element) and clamped channel indices keep the
         // scattered loads of a fragment free of branches, so they are issued back to back.
-        const size_t plane_out = (size_t)a.Hout * a.Wout;
-        const size_t vol_out = plane_out * a.Dout;
+        const size_t plane_out = (size_t)a.Hfull * a.Wfull;
+        const size_t vol_out = plane_out * a.Dfull;
         const size_t plane_res = (size_t)a.Hres * a.Wres;
         const size_t vol_res = plane_res * a.Dres;
         const int co0 = cog * C::MT + l4 * 4;
@@ -425,9 +431,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
             const int ox = x0 + (n % NFC) * 16 + l15;
             if ((oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout)) {
-                const size_t pix_res = (size_t)(C::DIMS == 3 ? oz + a.res_crop : 0) * plane_res +
-                                       (size_t)(oy + a.res_crop) * a.Wres + (ox + a.res_crop);
-                const size_t pix_out = (size_t)oz * plane_out + (size_t)oy * a.Wout + ox;
+                // position in the full output tensor (identity unless this is a phase launch)
+                const int fz = oz * a.os + a.ooz, fy = oy * a.os + a.ooy, fx = ox * a.os + a.oox;
+                const size_t pix_res = (size_t)(C::DIMS == 3 ? fz + a.res_crop : 0) * plane_res +
+                                       (size_t)(fy + a.res_crop) * a.Wres + (fx + a.res_crop);
+                const size_t pix_out = (size_t)fz * plane_out + (size_t)fy * a.Wfull + fx;
 #pragma unroll
                 for (int m = 0; m < MW; ++m) {
                     float v[4];
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
     if constexpr (EPI == EPI_HEAD) {
         // fused 1x1 head: reduce over the four 16-lane groups (they hold different co of the same pixel)
-        const size_t plane_o = (size_t)a.Hout * a.Wout;
+        const size_t plane_o = (size_t)a.Hfull * a.Wfull;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int trow = wave * C::RPW + n / NFC;
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             if (l4 == 0 && oy < a.Hout && ox < a.Wout && oz < a.Dout) {
                 h += a.head_b;
                 if (a.norm_out) h = h * out_scale + out_shift;
-                a.head_out[(size_t)oz * plane_o + (size_t)oy * a.Wout + ox] = h;
+                a.head_out[(size_t)(oz * a.os + a.ooz) * plane_o + (size_t)(oy * a.os + a.ooy) * a.Wfull + (ox * a.os + a.oox)] = h;
             }
         }
     }

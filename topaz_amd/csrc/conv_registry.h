@@ -56,7 +56,8 @@ struct ConvRegistrar {
 #define TPZ_CONV2D_HEAD(K, D, MT, TH, TW, KG, RPS)                                     \
     TPZ_CONV2D_EPI(K, D, MT, TH, TW, KG, RPS, false, ::tpz::EPI_PLAIN)                 \
     TPZ_CONV2D_EPI(K, D, MT, TH, TW, KG, RPS, false, ::tpz::EPI_HEAD)
-#define TPZ_CONV3D(K, D, MT, TD, TH, TW, KG, RPS, CIN1) \
-    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, TD, TH, TW, KG, RPS, CIN1, 3>, ::tpz::EPI_PLAIN> TPZ_CAT(tpz_reg_, __COUNTER__);
+#define TPZ_CONV3D_EPI(K, D, MT, TD, TH, TW, KG, RPS, CIN1, EPI) \
+    static ::tpz::ConvRegistrar<::tpz::ConvCfg<K, D, MT, TD, TH, TW, KG, RPS, CIN1, 3>, EPI> TPZ_CAT(tpz_reg_, __COUNTER__);
+#define TPZ_CONV3D(K, D, MT, TD, TH, TW, KG, RPS, CIN1) TPZ_CONV3D_EPI(K, D, MT, TD, TH, TW, KG, RPS, CIN1, ::tpz::EPI_PLAIN)
 
 }  // namespace tpz

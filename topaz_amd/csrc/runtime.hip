@@ -35,6 +35,8 @@ const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1, int e
 // context
 // ------------------------------------------------------------------------------------------------
 static std::string g_last_error;
+// TPZ_NO_PHASE=1 keeps the fused upsample+concat loader for every decoder layer (A/B switch for tests and tuning)
+static const bool g_no_phase = getenv("TPZ_NO_PHASE") != nullptr;
 
 struct ProfRec {
     int cls;
@@ -189,6 +191,16 @@ struct LayerRT {
     float* d_post_shift = nullptr;
     float* d_head_w = nullptr;
     float head_b = 0.f;
+    // phase decomposition (prepare_phases): the first source arrives 2x nearest-upsampled
+    struct Phase {
+        bool valid = false;
+        int c1 = 0, c2 = 0, k1 = 0;
+        const ConvKernelInfo* ki_low = nullptr;    // k1-tap kernel over the low-resolution source, EPI_PLAIN
+        const ConvKernelInfo* ki_skip = nullptr;   // k-tap kernel over the skip source, EPI_RES (in place)
+        int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
+        float* d_w_low[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        float* d_w_skip = nullptr;
+    } phase;
 };
 
 struct tpz_model {
@@ -226,6 +238,21 @@ static int upload(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** 
 static const int MT_CHOICES[] = {16, 32, 48, 64, 96, 128};
 
 // choose the MFMA instantiation for a conv layer; returns nullptr when the direct kernel must be used
+static const ConvKernelInfo* pick_conv(int dims, int k, int dil, int cout, bool cin1, int epi) {
+    const ConvKernelInfo* best = nullptr;
+    int best_padded = 1 << 30;
+    for (int mt : MT_CHOICES) {
+        const ConvKernelInfo* c = find_conv(dims, k, dil, mt, cin1, epi);
+        if (!c) continue;
+        const int padded = (cout + mt - 1) / mt * mt;
+        if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
+            best = c;
+            best_padded = padded;
+        }
+    }
+    return best;
+}
+
 static const ConvKernelInfo* choose_kernel(const tpz_layer& L) {
     if (L.cout == 1 && !L.head) return nullptr;      // M = 1: nothing for the matrix cores to do
     const bool cin1 = (L.cin == 1 && L.src2 < 0);
@@ -234,18 +261,7 @@ static const ConvKernelInfo* choose_kernel(const tpz_layer& L) {
     if (L.head) epi = EPI_HEAD;
     else if (L.res >= 0) epi = L.post_scale_off >= 0 ? EPI_RES_POST : EPI_RES;
     if ((L.head && (L.res >= 0 || L.post_scale_off >= 0)) || (L.res < 0 && L.post_scale_off >= 0)) return nullptr;
-    const ConvKernelInfo* best = nullptr;
-    int best_padded = 1 << 30;
-    for (int mt : MT_CHOICES) {
-        const ConvKernelInfo* k = find_conv(L.dims, L.k, L.dil, mt, cin1, epi);
-        if (!k) continue;
-        const int padded = (L.cout + mt - 1) / mt * mt;
-        if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
-            best = k;
-            best_padded = padded;
-        }
-    }
-    return best;
+    return pick_conv(L.dims, L.k, L.dil, L.cout, cin1, epi);
 }
 
 // weights [cout][cin][kz][ky][kx] -> per (co-group, channel chunk, stage) blocks in A-fragment lane order:
@@ -286,8 +302,71 @@ static void pack_weights(const ConvKernelInfo& ki, const float* w, int cout, int
             }
 }
 
+// Phase decomposition of conv(cat(upsample2x(a), b)) (the U-Net decoders, topaz/denoising/models.py:140-171).
+// A k-tap "same" convolution of a 2x nearest-upsampled tensor touches only k1 = k/2 + 1 distinct source
+// elements per axis; which ones, and with which sums of the original taps, depends on the parity p of the
+// output coordinate:   source index = o + t - pad_p,   t(ky) = floor((p + ky - k/2) / 2) + pad_p,
+// pad_p = -floor((p - k/2) / 2).  So the layer is run as 2^dims k1-tap convolutions over the LOW-resolution
+// source `a` (one per output parity, weights pre-summed in fp64, output written to the strided positions)
+// followed by the k-tap convolution of the skip source `b` alone, which adds itself in place and applies
+// bias + activation.  The zero padding agrees because the upsample is exact (full = 2 * low per axis);
+// run_conv() checks that at run time and otherwise keeps the fused upsample+concat loader.
+static int phase_pad(int k, int p) { return (k / 2 - p + 1) / 2; }
+static int phase_tap(int k, int p, int ky) {
+    const int v = p + ky - k / 2;                  // floor(v / 2) for negative v too
+    return (v >= 0 ? v / 2 : -((-v + 1) / 2)) + phase_pad(k, p);
+}
+
+static int prepare_phases(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const float* w, int c1, int c2,
+                          LayerRT& rt) {
+    LayerRT::Phase& ph = rt.phase;
+    if (L.src2 < 0 || L.dil != 1 || (L.k != 3 && L.k != 5) || L.pad != L.k / 2 || L.res >= 0 || L.head ||
+        L.post_scale_off >= 0 || c1 + c2 != L.cin || c1 < 1 || c2 < 1)
+        return 0;
+    const int k = L.k, k1 = k / 2 + 1, dims = L.dims;
+    ph.ki_low = pick_conv(dims, k1, 1, L.cout, false, EPI_PLAIN);
+    ph.ki_skip = pick_conv(dims, k, 1, L.cout, c2 == 1, EPI_RES);
+    if (!ph.ki_low || !ph.ki_skip) return 0;
+    ph.c1 = c1; ph.c2 = c2; ph.k1 = k1;
+    const int kz_n = dims == 3 ? k : 1, k1z_n = dims == 3 ? k1 : 1;
+    const size_t taps = (size_t)kz_n * k * k, taps1 = (size_t)k1z_n * k1 * k1;
+    ph.n_cog_low = (L.cout + ph.ki_low->MT - 1) / ph.ki_low->MT;
+    ph.n_chunks_low = (c1 + ph.ki_low->NCH - 1) / ph.ki_low->NCH;
+    ph.n_cog_skip = (L.cout + ph.ki_skip->MT - 1) / ph.ki_skip->MT;
+    ph.n_chunks_skip = ph.ki_skip->cin1 ? 1 : (c2 + ph.ki_skip->NCH - 1) / ph.ki_skip->NCH;
+    std::vector<double> acc;
+    std::vector<float> eff, packed;
+    const int n_phase = 1 << dims;
+    for (int p = 0; p < n_phase; ++p) {
+        const int px = p & 1, py = (p >> 1) & 1, pz = dims == 3 ? (p >> 2) & 1 : 0;
+        acc.assign((size_t)L.cout * c1 * taps1, 0.0);
+        for (int co = 0; co < L.cout; ++co)
+            for (int ci = 0; ci < c1; ++ci)
+                for (int kz = 0; kz < kz_n; ++kz)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const int tz = dims == 3 ? phase_tap(k, pz, kz) : 0;
+                            const int ty = phase_tap(k, py, ky), tx = phase_tap(k, px, kx);
+                            acc[((size_t)co * c1 + ci) * taps1 + ((size_t)tz * k1 + ty) * k1 + tx] +=
+                                (double)w[((size_t)co * L.cin + ci) * taps + ((size_t)kz * k + ky) * k + kx];
+                        }
+        eff.resize(acc.size());
+        for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
+        pack_weights(*ph.ki_low, eff.data(), L.cout, c1, ph.n_cog_low, ph.n_chunks_low, packed);
+        if (upload(ctx, m, packed.data(), packed.size(), &ph.d_w_low[p])) return 1;
+    }
+    eff.resize((size_t)L.cout * c2 * taps);
+    for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < c2; ++ci)
+            memcpy(&eff[((size_t)co * c2 + ci) * taps], &w[((size_t)co * L.cin + c1 + ci) * taps], taps * sizeof(float));
+    pack_weights(*ph.ki_skip, eff.data(), L.cout, c2, ph.n_cog_skip, ph.n_chunks_skip, packed);
+    if (upload(ctx, m, packed.data(), packed.size(), &ph.d_w_skip)) return 1;
+    ph.valid = true;
+    return 0;
+}
+
 static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const float* blob, size_t n_floats,
-                         LayerRT& rt) {
+                         LayerRT& rt, int c1 = 0, int c2 = 0) {
     rt.L = L;
     if (L.op != TPZ_OP_CONV) return 0;
     if (L.dims != 2 && L.dims != 3) return fail(ctx, "conv: dims must be 2 or 3");
@@ -304,6 +383,7 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
         std::vector<float> packed;
         pack_weights(ki, w, L.cout, L.cin, rt.n_cog, rt.n_chunks, packed);
         if (upload(ctx, m, packed.data(), packed.size(), &rt.d_wpk)) return 1;
+        if (!g_no_phase && prepare_phases(ctx, m, L, w, c1, c2, rt)) return 1;
     } else {
         if (L.src2 >= 0 || L.res >= 0 || L.head || L.post_scale_off >= 0)
             return fail(ctx, "conv k=%d dil=%d cin=%d cout=%d dims=%d: no MFMA kernel compiled and the direct "
@@ -328,6 +408,71 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
 // ------------------------------------------------------------------------------------------------
 // executor
 // ------------------------------------------------------------------------------------------------
+// grid, XCD swizzle and phase stagger of one conv_mfma launch; a.Dout/Hout/Wout, n_chunks, cog_inner are set
+static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int n_cog, double flops) {
+    a.xcd_swizzle = 1;
+    a.tiles_x = (a.Wout + ki.TW - 1) / ki.TW;
+    a.tiles_y = (a.Hout + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
+    a.tiles_z = ki.dims == 3 ? (a.Dout + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
+    a.stagger_first = a.stagger_sleeps = 0;
+    // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
+    if ((long long)a.tiles_x * a.tiles_y >= 4096) {
+        a.stagger_first = 512;
+        a.stagger_sleeps = (int)((long long)a.n_chunks * ki.SPG * ki.STEPS * (ki.MT / 16) *
+                                 ((ki.TD * ki.TH / 4) * (ki.TW / 16)) * 32 / 8128 / 2);
+    }
+    if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
+    dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, n_cog / a.cog_inner);
+    prof_begin(ctx, 0, flops, &ki);
+    hipError_t e = ki.launch(a, grid, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+// conv(cat(upsample2x(s1), s2)) by output parity (prepare_phases): 2^dims plain launches over s1 that write the
+// strided output positions, then the skip-source launch over the full grid that adds itself in place.
+static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base, const Slot& s1, const Slot& s2,
+                           Slot& dst) {
+    const tpz_layer& L = rt.L;
+    const LayerRT::Phase& ph = rt.phase;
+    const int n_phase = 1 << L.dims;
+    for (int p = 0; p < n_phase; ++p) {
+        const int px = p & 1, py = (p >> 1) & 1, pz = L.dims == 3 ? (p >> 2) & 1 : 0;
+        ConvArgs a = base;
+        a.in2 = nullptr;
+        a.wpk = ph.d_w_low[p];
+        a.bias = nullptr;
+        a.res = nullptr;
+        a.nrm = nullptr;
+        a.norm_out = 0;
+        a.slope = 1.f;
+        a.Cin = a.Cin1 = ph.c1;
+        a.Din = a.D1 = s1.D; a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
+        a.Dout = s1.D; a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of this parity
+        a.pad_x = phase_pad(L.k, px); a.pad_y = phase_pad(L.k, py); a.pad_z = L.dims == 3 ? phase_pad(L.k, pz) : 0;
+        a.pad = a.pad_x;
+        a.os = 2; a.oox = px; a.ooy = py; a.ooz = pz;
+        a.n_chunks = ph.n_chunks_low;
+        a.cog_inner = 1;
+        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W;
+        if (launch_mfma(ctx, *ph.ki_low, a, ph.n_cog_low, fl)) return 1;
+    }
+    ConvArgs a = base;
+    a.in = s2.p;
+    a.in2 = nullptr;
+    a.wpk = ph.d_w_skip;
+    a.res = dst.p;                                                     // in place: every thread reads what it writes
+    a.Dres = dst.D; a.Hres = dst.H; a.Wres = dst.W; a.res_crop = 0;
+    a.Cin = a.Cin1 = ph.c2;
+    a.D1 = s2.D; a.H1 = s2.H; a.W1 = s2.W;
+    a.cs1 = s2.cs; a.ps1 = s2.ps; a.pitch1 = s2.pitch;
+    a.n_chunks = ph.n_chunks_skip;
+    a.cog_inner = 1;
+    const double fl = 2.0 * L.cout * ph.c2 * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    return launch_mfma(ctx, *ph.ki_skip, a, ph.n_cog_skip, fl);
+}
+
 static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* s2, const Slot* sres, Slot& dst,
                     const float* d_nrm, int norm_out) {
     const tpz_layer& L = rt.L;
@@ -355,6 +500,9 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.Cout = L.cout;
     a.Dout = dst.D; a.Hout = dst.H; a.Wout = dst.W;
     a.pad = L.pad;
+    a.pad_x = a.pad_y = a.pad_z = L.pad;
+    a.os = 1;
+    a.Dfull = dst.D; a.Hfull = dst.H; a.Wfull = dst.W;
     if (sres) { a.Dres = sres->D; a.Hres = sres->H; a.Wres = sres->W; a.res_crop = L.res_crop; }
     a.slope = L.slope;
     if (L.head) { a.head_out = dst.p; a.out = nullptr; }
@@ -362,28 +510,15 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
     if (rt.ki) {
         const ConvKernelInfo& ki = *rt.ki;
+        const LayerRT::Phase& ph = rt.phase;
+        if (ph.valid && s2 && s1.C == ph.c1 && s2->C == ph.c2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W &&
+            (L.dims == 2 || s2->D == 2 * s1.D))
+            return run_conv_phases(ctx, rt, a, s1, *s2, dst);
         if (s2 && (s1.C % ki.NCH) != 0)
             return fail(ctx, "fused concat needs the first source's channels (%d) to be a multiple of %d", s1.C, ki.NCH);
         a.n_chunks = rt.n_chunks;
         a.cog_inner = rt.cog_inner;
-        a.xcd_swizzle = 1;
-        {   // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
-            const long long wgs = (long long)((dst.W + ki.TW - 1) / ki.TW) * ((dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D);
-            if (wgs >= 4096) {
-                a.stagger_first = 512;
-                a.stagger_sleeps = (int)((long long)rt.n_chunks * ki.SPG * ki.STEPS * (ki.MT / 16) *
-                                         ((ki.TD * ki.TH / 4) * (ki.TW / 16)) * 32 / 8128 / 2);
-            }
-        }
-        a.tiles_x = (dst.W + ki.TW - 1) / ki.TW;
-        a.tiles_y = (dst.H + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
-        a.tiles_z = L.dims == 3 ? (dst.D + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
-        if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
-        dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, rt.n_cog / rt.cog_inner);
-        prof_begin(ctx, 0, flops, &ki);
-        hipError_t e = ki.launch(a, grid, ctx->stream);
-        prof_end(ctx);
-        HIPCHK(ctx, e);
+        if (launch_mfma(ctx, ki, a, rt.n_cog, flops)) return 1;
     } else {
         if (s1.D != geo.D || s1.H != geo.H || s1.W != geo.W) return fail(ctx, "direct conv cannot upsample");
         prof_begin(ctx, 1, flops);
@@ -526,8 +661,17 @@ int tpz_ctx_sync(tpz_ctx* ctx) {
     return 0;
 }
 
+static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
+                      const std::vector<int>& preset_chan, tpz_model** out);
+
 int tpz_model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
                    tpz_model** out) {
+    return model_load(ctx, layers, n_layers, h_blob, n_floats, {1}, out);    // slot 0 = the 1-channel input
+}
+
+// preset_chan: channels of the externally provided slots (slot 0, and tpz_conv's extra sources)
+static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
+                      const std::vector<int>& preset_chan, tpz_model** out) {
     if (!ctx || !layers || !out || n_layers < 1) return fail(ctx, "tpz_model_load: bad arguments");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -542,12 +686,16 @@ int tpz_model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const fl
     m->n_slots = max_slot + 1;
     m->last_use.assign(m->n_slots, -1);
     m->layers.resize(n_layers);
+    std::vector<int> chan(m->n_slots, 0);       // channels of every slot
+    for (size_t i = 0; i < preset_chan.size() && i < chan.size(); ++i) chan[i] = preset_chan[i];
     for (int i = 0; i < n_layers; ++i) {
         const tpz_layer& L = layers[i];
         m->last_use[L.src] = i;
         if (L.src2 >= 0) m->last_use[L.src2] = i;
         if (L.res >= 0) m->last_use[L.res] = i;
-        if (prepare_layer(ctx, m, L, h_blob, n_floats, m->layers[i])) { tpz_model_free(m); return 1; }
+        const int c1 = chan[L.src], c2 = L.src2 >= 0 ? chan[L.src2] : 0;
+        if (prepare_layer(ctx, m, L, h_blob, n_floats, m->layers[i], c1, c2)) { tpz_model_free(m); return 1; }
+        chan[L.dst] = L.op == TPZ_OP_CONV ? (L.head ? 1 : L.cout) : c1;
     }
     *out = m;
     return 0;
@@ -779,7 +927,7 @@ int tpz_conv(tpz_ctx* ctx, int dims, const float* d_in, int cin1, int D1, int H1
         L.head_b_off = (int64_t)blob.size(); blob.push_back(head_b);
     }
     tpz_model* m = nullptr;
-    if (tpz_model_load(ctx, &L, 1, blob.data(), blob.size(), &m)) return 1;
+    if (model_load(ctx, &L, 1, blob.data(), blob.size(), {cin1, d_in2 ? cin - cin1 : 0, cout}, &m)) return 1;
     std::vector<Slot> slots(4);
     set_dense(slots[0], const_cast<float*>(d_in), cin1, D1, H1, W1);
     if (d_in2) set_dense(slots[1], const_cast<float*>(d_in2), cin - cin1, D, H, W);
