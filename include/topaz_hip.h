@@ -152,6 +152,10 @@ int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double*
 /* the conv_mfma instantiation with the largest accumulated time since the last reset: total ms, launch count,
  * algorithmic FLOP of those launches and its template parameters as text (matches the rocprofv3 kernel name) */
 int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len);
+/* the same for the rank-th instantiation by accumulated time (rank 0 = the dominant one); an empty name and zeros
+ * once rank runs past the instantiations that were launched */
+int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches, double* flops, char* name,
+                        int name_len);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ _SIGNATURES = {
     'tpz_prof_enable': (C.c_int, [_P, C.c_int]),
     'tpz_prof_reset': (C.c_int, [_P]),
     'tpz_prof_get_dominant': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_int]),
+    'tpz_prof_get_kernel': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     'tpz_prof_get': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
 }
 

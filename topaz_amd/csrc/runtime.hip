@@ -1086,26 +1086,32 @@ int tpz_prof_reset(tpz_ctx* ctx) {
     ctx->per_kernel.clear();
     return 0;
 }
-int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len) {
-    if (!ctx) return fail(nullptr, "ctx is NULL");
+int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches, double* flops, char* name,
+                        int name_len) {
+    if (!ctx || rank < 0) return fail(ctx, "tpz_prof_get_kernel: bad arguments");
     prof_flush(ctx);
-    const void* best = nullptr;
-    ProfAcc acc;
-    for (auto& kv : ctx->per_kernel)
-        if (kv.second.ms > acc.ms) { best = kv.first; acc = kv.second; }
+    std::vector<std::pair<const void*, ProfAcc>> order(ctx->per_kernel);
+    std::stable_sort(order.begin(), order.end(),
+                     [](const std::pair<const void*, ProfAcc>& x, const std::pair<const void*, ProfAcc>& y) {
+                         return x.second.ms > y.second.ms;
+                     });
+    const bool have = rank < (int)order.size();
+    const ProfAcc acc = have ? order[rank].second : ProfAcc();
     if (ms) *ms = acc.ms;
     if (launches) *launches = acc.n;
     if (flops) *flops = acc.flops;
     if (name && name_len > 0) {
-        if (best) {
-            const ConvKernelInfo* k = (const ConvKernelInfo*)best;
+        name[0] = 0;
+        if (have) {
+            const ConvKernelInfo* k = (const ConvKernelInfo*)order[rank].first;
             snprintf(name, name_len, "conv_mfma_kernel<K=%d,D=%d,MT=%d,TD=%d,TH=%d,TW=%d,KG=%d,RPS=%d,CIN1=%d,DIMS=%d,EPI=%d>",
                      k->K, k->D, k->MT, k->TD, k->TH, k->TW, k->KG, k->RPS, k->cin1, k->dims, k->epi);
-        } else {
-            name[0] = 0;
         }
     }
     return 0;
+}
+int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len) {
+    return tpz_prof_get_kernel(ctx, 0, ms, launches, flops, name, name_len);
 }
 int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops) {
     if (!ctx || cls < 0 || cls > 3) return fail(ctx, "tpz_prof_get: bad arguments");

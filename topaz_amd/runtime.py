@@ -79,7 +79,22 @@ def _prof_get_dominant(self):
     return buf.value.decode(), ms.value, n.value, fl.value
 
 
+def _prof_kernels(self):
+    """[(name, total ms, launches, FLOP)] of every conv_mfma instantiation launched since the last reset,
+    by accumulated time"""
+    out = []
+    while True:
+        ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+        buf = C.create_string_buffer(256)
+        check(self.lib.tpz_prof_get_kernel(self.handle, len(out), C.byref(ms), C.byref(n), C.byref(fl), buf, 256),
+              self.handle)
+        if not buf.value:
+            return out
+        out.append((buf.value.decode(), ms.value, n.value, fl.value))
+
+
 Context.prof_get_dominant = _prof_get_dominant
+Context.prof_kernels = _prof_kernels
 
 
 def get_context(device: Optional[int] = None) -> Context:
