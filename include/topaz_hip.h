@@ -143,6 +143,21 @@ int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H,
 int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float* d_out);
 
 /* ---- introspection / measurement --------------------------------------------------------- */
+/* ---- 2xf16 path.  Scoring networks (1-channel stem, single-source 2-D convs, fused head) run by default on the
+ * f16 matrix cores with every fp32 operand carried as two f16 halves and three exact products accumulated in fp32
+ * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  An activation beyond
+ * the f16 range is detected on the device and that image is re-run on the fp32 kernels, so results never depend
+ * on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1 in the environment) pins the fp32 kernels.
+ * tpz_model_split_stats: whether the model is eligible, images finished on the 2xf16 path, images re-run in fp32. */
+int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
+int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns);
+/* One 2-D convolution on the 2xf16 kernels with fp32 [C][H][W] tensors at the boundary (converted on the device):
+ * unit-test / interop entry; arguments as tpz_conv (single source).  *overflow = 1 when a result left the f16 range. */
+int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, const float* h_w, const float* h_b,
+                      int cout, int k, int dil, int pad, float slope, const float* d_res, int res_crop,
+                      const float* h_post_scale, const float* h_post_shift, const float* h_head_w, float head_b,
+                      float* d_out, int* overflow);
+
 /* time (ms, HIP events on the ctx stream) and launch count of the kernels of one class since
  * the last reset.  cls: 0 = conv_mfma, 1 = conv_direct, 2 = elementwise, 3 = nms.
  * Timing is only collected while enabled (it adds two event records per launch). */

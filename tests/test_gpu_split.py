@@ -1,0 +1,156 @@
+"""The 2xf16 path (topaz_amd/csrc/conv_split.h): every fp32 operand carried as two f16 halves, three exact
+products accumulated in fp32 on v_mfma_f32_16x16x32_f16.  Same tolerance as the fp32 kernels: 1e-4 * (1 + |ref|)
+against torch-CPU fp32 / the oracle; plus a direct comparison with a float64 evaluation showing the error is at
+the fp32 level, and the f16-range fallback."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+
+
+def _act(y, slope):
+    return torch.where(y > 0, y, y * slope)
+
+
+SPLIT_CASES = [
+    # cin, cout, k, dil, H, W, slope
+    (128, 128, 5, 4, 70, 81, 0.0),      # K5 D4 (plain epilogue of the head layer's kernel)
+    (64, 128, 1, 1, 33, 47, 1.0),       # 1x1 projection
+    (128, 128, 3, 4, 60, 75, 0.0),
+    (128, 128, 3, 8, 70, 66, 0.0),
+    (64, 128, 3, 2, 45, 50, 0.0),
+    (64, 64, 3, 1, 40, 41, 0.0),
+    (64, 64, 3, 2, 64, 64, 0.0),
+    (64, 64, 3, 4, 37, 130, 0.25),
+    (128, 256, 5, 4, 40, 49, 0.0),      # two co-groups
+    (72, 100, 3, 4, 41, 43, 0.0),       # channels that are not multiples of the cell / tile sizes
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv_split(gpu_ctx, case):
+    from topaz_amd import runtime as rt
+    cin, cout, k, dil, H, W, slope = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(cin, H, W, generator=g) * 3
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    w[0] *= 1e-3                                         # per-channel weight scaling must cope with both
+    w[1] *= 50
+    b = torch.randn(cout, generator=g)
+    ref64 = _act(F.conv2d(x[None].double(), w.double(), b.double(), dilation=dil), slope)[0]
+    ref32 = _act(F.conv2d(x[None], w, b, dilation=dil), slope)[0]
+    y, ovf = rt.conv_split(x, w.numpy(), b.numpy(), dil=dil, slope=slope)
+    assert not ovf
+    e_split, e_f32 = _err(y, ref64), _err(ref32, ref64)
+    assert _err(y, ref32) <= 1e-4
+    assert e_split <= max(4 * e_f32, 2e-6), (e_split, e_f32)    # fp32-level accuracy, not f16-level
+
+
+def test_conv_split_residual_bn(gpu_ctx):
+    from topaz_amd import runtime as rt
+    g = torch.Generator().manual_seed(32)
+    cin, cout, H, W, d, crop = 64, 128, 70, 60, 4, 6
+    x = torch.randn(cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    Ho, Wo = H - 2 * d, W - 2 * d
+    res = torch.randn(cout, Ho + 2 * crop, Wo + 2 * crop, generator=g)
+    ps, pt = 1 + 0.1 * torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    y0 = F.conv2d(x[None], w, b, dilation=d)[0] + res[:, crop:-crop, crop:-crop]
+    for post in (False, True):
+        ref = F.relu(y0 * ps[:, None, None] + pt[:, None, None]) if post else F.relu(y0)
+        y, ovf = rt.conv_split(x, w.numpy(), b.numpy(), dil=d, slope=0.0, res=res, res_crop=crop,
+                               post_scale=ps.numpy() if post else None, post_shift=pt.numpy() if post else None)
+        assert not ovf and _err(y, ref) <= 1e-4
+
+
+@pytest.mark.parametrize('cout', [256, 200])
+def test_conv_split_fused_head(gpu_ctx, cout):
+    from topaz_amd import runtime as rt
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(128, 50, 77, generator=g)
+    w = torch.randn(cout, 128, 5, 5, generator=g) / np.sqrt(128 * 25)
+    b = torch.randn(cout, generator=g)
+    hw = torch.randn(cout, generator=g) / np.sqrt(cout)
+    feat = F.relu(F.conv2d(x[None], w, b, dilation=4))
+    ref = F.conv2d(feat, hw.view(1, cout, 1, 1), torch.tensor([0.7]))[0]
+    y, _ = rt.conv_split(x, w.numpy(), b.numpy(), dil=4, slope=0.0, head_w=hw.numpy(), head_b=0.7)
+    assert _err(y, ref) <= 1e-4
+
+
+def test_conv_split_padding_and_overflow_flag(gpu_ctx):
+    from topaz_amd import runtime as rt
+    g = torch.Generator().manual_seed(34)
+    x = torch.randn(64, 20, 45, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    ref = F.conv2d(x[None], w, None, padding=1)[0]
+    y, ovf = rt.conv_split(x, w.numpy(), None, pad=1, slope=1.0)
+    assert not ovf and _err(y, ref) <= 1e-4
+    y, ovf = rt.conv_split(x * 1e5, w.numpy(), None, pad=1, slope=1.0)        # outputs ~1e5 > 65504
+    assert ovf
+
+
+def _resnet(arch, units, bn, seed=7):
+    from oracle import scoring as oscoring
+    from topaz_amd.model.classifier import LinearClassifier
+    sd = oscoring.synthetic_resnet_sd(arch, units, seed, bn=bn)
+    m = LinearClassifier(arch, sd)
+    m.eval(); m.fill(); m.cuda()
+    return m, sd
+
+
+@pytest.mark.parametrize('arch,bn', [('resnet8', False), ('resnet8', True), ('resnet16', False)])
+def test_resnet_u64_runs_split_and_matches_oracle(gpu_ctx, arch, bn):
+    """A whole filled ResNet at 64 units goes down the 2xf16 path (stats say so) and agrees with the oracle and
+    with the pinned fp32 kernels."""
+    from oracle import scoring as oscoring
+    m, sd = _resnet(arch, 64, bn)
+    x = np.random.RandomState(3).randn(150, 161).astype(np.float32)
+    ref = oscoring.score(arch, sd, x)
+    xt = torch.from_numpy(x).cuda()[None, None]
+    dm = m.device_model
+    before = dm.split_stats()
+    assert before[0], 'model should be eligible for the 2xf16 path'
+    y = m(xt)[0, 0].cpu().numpy()
+    after = dm.split_stats()
+    assert after[1] == before[1] + 1 and after[2] == before[2]
+    assert _err(y, ref) <= 1e-4
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = m(xt)[0, 0].cpu().numpy()
+        assert dm.split_stats()[1] == after[1]
+    finally:
+        gpu_ctx.set_exact(False)
+    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+
+
+def test_out_of_range_activations_rerun_in_fp32(gpu_ctx):
+    """Input scaled so that feature maps exceed 65504: the device flag trips and the image is re-run on the
+    fp32 kernels -- the scores still match the oracle."""
+    from oracle import scoring as oscoring
+    m, sd = _resnet('resnet8', 64, False)
+    x = (np.random.RandomState(4).randn(140, 150) * 3e4).astype(np.float32)
+    ref = oscoring.score('resnet8', sd, x)
+    dm = m.device_model
+    before = dm.split_stats()
+    y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    after = dm.split_stats()
+    assert after[2] == before[2] + 1, 'expected the fp32 re-run'
+    assert np.isfinite(y).all()
+    # logits scale with the input here (~1e5): compare relative to their magnitude
+    assert float(np.abs(y - ref).max()) <= 1e-5 * float(np.abs(ref).max())
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    finally:
+        gpu_ctx.set_exact(False)
+    assert np.array_equal(y, y32), 'the re-run must be the fp32 path itself'

@@ -58,6 +58,10 @@ _SIGNATURES = {
                            C.c_float, _P]),
     'tpz_maxpool2': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_transpose_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    'tpz_ctx_set_exact': (C.c_int, [_P, C.c_int]),
+    'tpz_model_split_stats': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'tpz_conv_split_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_int)]),
     'tpz_prof_enable': (C.c_int, [_P, C.c_int]),
     'tpz_prof_reset': (C.c_int, [_P]),
     'tpz_prof_get_dominant': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_int]),

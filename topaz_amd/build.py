@@ -39,9 +39,21 @@ def _headers_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs if os.path.exists(h))
 
 
+def _deps_mtime(obj: str, fallback: float) -> float:
+    """newest in-tree header the object was compiled from (hipcc -MD depfile); every header when unknown"""
+    dep = obj[:-2] + '.d'
+    if not os.path.exists(dep):
+        return fallback
+    names = open(dep).read().replace('\\\n', ' ').split()[1:]
+    root = os.path.abspath(os.path.join(HERE, '..'))
+    times = [os.path.getmtime(n) for n in names
+             if n.endswith('.h') and os.path.abspath(n).startswith(root) and os.path.exists(n)]
+    return max(times) if times else fallback
+
+
 def _compile(hipcc: str, src: str, obj: str) -> None:
     cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-           '-I', CSRC, '-c', src, '-o', obj]
+           '-I', CSRC, '-MD', '-MF', obj[:-2] + '.d', '-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
@@ -58,7 +70,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         src = os.path.join(CSRC, f)
         obj = os.path.join(BUILD, f[:-4] + '.o')
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), _deps_mtime(obj, hdr_t)):
             todo.append((src, obj))
     if todo:
         if verbose:

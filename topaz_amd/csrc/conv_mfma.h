@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "split_fmt.h"
+
 namespace tpz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -42,6 +44,7 @@ struct ConvArgs {
     float* head_out;          // [Dout][Hout][Wout]
     const float* zeros;       // >= 16 bytes of zeros in global memory (source of padded / OOB elements)
     const float* nrm;         // device float[4] {in_scale, in_shift, out_scale, out_shift} or nullptr
+    unsigned* flag;           // EPI_SPLIT: set to 1 when a stored value leaves the f16 range
     float head_b;
     int norm_out;             // y' = y*out_scale+out_shift applied last
     int Cin, Cin1;            // Cin1 = channels taken from `in` (== Cin when no concat)
@@ -151,7 +154,8 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // EPI selects the epilogue the kernel is compiled for (one lean, branch-free code path each):
 //   0 bias + activation            1 + residual add (ResidA skip)
 //   2 + residual + eval-BN affine  3 bias + activation + fused 1x1 head
-enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_RES_POST = 2, EPI_HEAD = 3 };
+//   4 bias + activation, output stored as split f16 cells for the 2xf16 path (split_fmt.h, conv_split.h)
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_RES_POST = 2, EPI_HEAD = 3, EPI_SPLIT = 4 };
 
 template <class C, int EPI = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
@@ -424,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         const size_t vol_res = plane_res * a.Dres;
         const int co0 = cog * C::MT + l4 * 4;
         const bool has_bias = a.bias != nullptr;
+        bool big = false;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int trow = wave * C::RPW + n / NFC;             // tile row, z-major
@@ -451,6 +456,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     }
                     if constexpr (EPI == EPI_HEAD) {
                         hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    } else if constexpr (EPI == EPI_SPLIT) {
+                        // the lane's 4 consecutive channels are half of a 16-byte cell (hi plane, then lo plane)
+                        const int c4 = co0 + m * 16;
+                        const int cell = c4 >> 3, half = (c4 >> 2) & 1;
+                        const int cells_out = (a.Cout + 7) >> 3;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (c4 + r >= a.Cout) v[r] = 0.f;
+                            big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
+                        }
+                        if (cell < cells_out) {
+                            uint2 hi, lo;
+                            split4(v, hi, lo);
+                            uint2* op = reinterpret_cast<uint2*>(reinterpret_cast<uint4*>(a.out) + (size_t)cell * vol_out + pix_out) + half;
+                            op[0] = hi;
+                            op[(size_t)cells_out * vol_out * 2] = lo;
+                        }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -462,6 +484,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                     }
                 }
             }
+        }
+        if constexpr (EPI == EPI_SPLIT) {
+            if (__any(big) && lane == 0) atomicOr(a.flag, 1u);
         }
     }  // co-group loop
 

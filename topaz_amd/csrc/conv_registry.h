@@ -2,6 +2,7 @@
 // unit registers its kernels at load time; the runtime picks one by (dims, K, dil, MT, CIN1).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include "conv_mfma.h"
 
 namespace tpz {
@@ -10,6 +11,7 @@ struct ConvKernelInfo {
     int dims, K, D, MT, cin1, epi;
     int TD, TH, TW, KG, RPS, KP, KXG, NCH, SPG, STEPS, W_STAGE, W_CHUNK, lds_bytes;
     hipError_t (*launch)(const ConvArgs&, dim3 grid, hipStream_t);
+    char name[160];           // template parameters as text (profiler key; matches the rocprofv3 kernel name)
 };
 
 void register_conv(const ConvKernelInfo& info);
@@ -37,6 +39,8 @@ struct ConvRegistrar {
         i.NCH = C::NCH; i.SPG = C::SPG; i.STEPS = C::STEPS; i.W_STAGE = C::W_STAGE; i.W_CHUNK = C::W_CHUNK;
         i.lds_bytes = C::LDS_BYTES;
         i.launch = &launch_conv_cfg<C, EPI>;
+        snprintf(i.name, sizeof i.name, "conv_mfma_kernel<K=%d,D=%d,MT=%d,TD=%d,TH=%d,TW=%d,KG=%d,RPS=%d,CIN1=%d,DIMS=%d,EPI=%d>",
+                 i.K, i.D, i.MT, i.TD, i.TH, i.TW, i.KG, i.RPS, i.cin1, i.dims, i.epi);
         register_conv(i);
     }
 };

@@ -1,0 +1,335 @@
+// fp32-accurate implicit-GEMM convolution on the f16 matrix cores of CDNA4 (v_mfma_f32_16x16x32_f16).
+//
+// The dilated convolutions of the filled scoring networks (topaz/model/features/resnet.py:129-133,185-202,
+// 294-302; topaz/model/features/basic.py:47-63) dominate `topaz extract`; on the fp32 MFMA path
+// (conv_mfma.h) they sit at ~93 % of a 157 TFLOP/s peak.  The f16 MFMA issues 16x the MACs per cycle, so
+// every fp32 operand is carried as two f16 halves (split_fmt.h) and each product is formed as
+//     w*x  ~=  wh*xh + wh*xl + wl*xh          (the dropped wl*xl term is < 2^-22 |w*x|)
+// -- three exact f16 products accumulated in fp32: 16/3 = 5.3x the fp32-MFMA rate at equal accuracy
+// (the split carries 22 mantissa bits, fp32 24; the measured error against a float64 evaluation is
+// below that of an fp32 evaluation of the same network, tests/test_gpu_split.py).  Weights are scaled per
+// output channel by a power of two before splitting (undone exactly in the epilogue) so that their lo
+// halves stay normal f16 numbers.  Activations beyond the f16 range raise a device flag; the runtime then
+// re-runs the forward pass on the fp32 kernels (runtime.hip).
+//
+// GEMM view: M = output channels, N = output pixels, K = Cin * taps.  One MFMA covers 32 K-elements:
+//   lane (i, kb) holds 8 consecutive K values; kb = 0..3 selects a "slot" = (tap, 8-channel cell), the 8
+//   values are the cell's channels.  B operand = one 16-byte cell of the LDS tile (ds_read_b128), A operand
+//   = 16 bytes of host-packed weights.  A chunk of the K loop is CC cells (8*CC channels) x all taps, cut
+//   into steps of 4 slots (SplitCfg::slot): with CC even the slot pairs (kb 0,1) and (kb 2,3) are the two
+//   cells of one tap; with CC = 1 they are vertically adjacent taps.  Either way the two 16-byte reads of a
+//   ds_read_b128 lane group are a multiple of 256 bytes apart: conflict-free (MI355X_MICROARCH.md, LDS).
+// Workgroup = 512 threads = 8 waves (two per SIMD), one per CU; tile = MT output channels x (TH x TW)
+//   pixels, rows strided by the dilation as in conv_mfma.h.  Wave tile = MT x (TH/8 rows x TW) pixels:
+//   per step 2*MW + 2*NW ds_read_b128 feed 3*MW*NW MFMAs.
+// Pipeline: one stage = one step.  Weights of step s+1 and, spread over the steps of a chunk, the input
+//   tile of the next chunk arrive by LDS-DMA (global_load_lds_dwordx4: one cell per lane) into the other
+//   LDS buffers while step s computes; one barrier per step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "conv_mfma.h"
+#include "split_fmt.h"
+
+namespace tpz {
+
+struct SplitArgs {
+    const uint4* in;          // split tensor: [2 planes][cells_in][Hin][Win] cells
+    const uint4* wpk;         // packed weights (runtime.hip pack_weights_split)
+    const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling
+    const float* bias;        // [Cout] or nullptr
+    uint4* out;               // split tensor [2][cells_out][Hout][Wout] (nullptr when the head is fused)
+    const uint4* res;         // split residual [2][cells_out][Hres][Wres] or nullptr
+    const float* post_scale;  // [Cout] affine after the residual add (eval BN) or nullptr
+    const float* post_shift;
+    const float* head_w;      // fused 1x1 head: [Cout]
+    float* head_out;          // fp32 [Hout][Wout]
+    const void* zeros;        // >= 16 bytes of zeros (source of padded / outside cells)
+    unsigned* flag;           // set to 1 when a stored activation leaves the f16 range
+    float head_b, slope;
+    int cells_in, Hin, Win;
+    int Cout, cells_out, Hout, Wout;
+    int pad;
+    int Hres, Wres, res_crop;
+    int n_chunks;             // chunks of CC cells
+    int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
+    int tiles_x, tiles_y;
+    int xcd_swizzle;
+};
+
+struct SplitSlot {
+    int ky, kx, c;            // ky < 0: padding slot (zero weights)
+};
+
+template <int K_, int D_, int MT_, int TH_, int TW_, int CC_>
+struct SplitCfg {
+    static constexpr int K = K_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
+    static constexpr int WAVES = 8, THREADS = 512;
+    static constexpr int MW = MT / 16;
+    static constexpr int RPW = TH / WAVES;
+    static constexpr int NFC = TW / 16;
+    static constexpr int NW = RPW * NFC;
+    static constexpr int ITH = TH + K - 1;
+    static constexpr int ITW = (TW + (K - 1) * D + 15) / 16 * 16;   // rows start on the same LDS bank slot
+    static constexpr int CELL_STRIDE = ITH * ITW;                   // cells per 8-channel cell plane (x16)
+    static constexpr int NPC = CC * CELL_STRIDE;                    // cells per (hi | lo) plane of a chunk
+    static constexpr int PLANE_BYTES = NPC * 16;
+    static constexpr int IN_BUF = 2 * PLANE_BYTES;
+    static constexpr int NR = (NPC + THREADS - 1) / THREADS;        // DMA rounds per plane
+    // ---- slots
+    static constexpr bool ROWPAIR = (K == 5) && ((4 * D) % 16 == 0);    // last-row taps kx = 0 and 4 pair up
+    static constexpr int PV = K * (K / 2);                              // vertical tap pairs (CC == 1)
+    static constexpr int PAIRS1 = PV + ((K % 2) ? (ROWPAIR ? K - 1 : K) : 0);
+    static constexpr int NSTEP = (CC == 1) ? (PAIRS1 + 1) / 2 : (K * K * CC + 3) / 4;
+    __host__ __device__ static constexpr SplitSlot slot(int step, int kb) {
+        if (CC != 1) {
+            const int q = step * 4 + kb, t = q / CC;
+            return t < K * K ? SplitSlot{t / K, t % K, q % CC} : SplitSlot{-1, 0, 0};
+        }
+        const int p = step * 2 + (kb >> 1), j = kb & 1;
+        if (p < PV) return SplitSlot{2 * (p % (K / 2)) + j, p / (K / 2), 0};
+        const int e = p - PV;
+        if (K % 2 == 0) return SplitSlot{-1, 0, 0};
+        if (ROWPAIR) {
+            if (e == 0) return SplitSlot{K - 1, j ? 4 : 0, 0};
+            return (e < K - 1 && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
+        }
+        return (e < K && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
+    }
+    __host__ __device__ static constexpr int slot_lds_off(int step, int kb) {
+        SplitSlot s = slot(step, kb);
+        if (s.ky < 0) s = slot(step, kb & ~1);          // padding reads its partner's cell (weights are zero)
+        if (s.ky < 0) return 0;
+        return (s.c * CELL_STRIDE + s.ky * ITW + s.kx * D) * 16;
+    }
+    static constexpr int W_STEP_BYTES = 2 * MW * 1024;              // hi + lo A fragments of one step
+    static constexpr int WR = W_STEP_BYTES / (THREADS * 16);        // DMA rounds per weight step
+    static constexpr int OFF_W = 2 * IN_BUF;
+    static constexpr int OFF_TAB = OFF_W + 2 * W_STEP_BYTES;
+    static constexpr int OFF_SLOT = OFF_TAB + NPC * 4;
+    static constexpr int LDS_BYTES = OFF_SLOT + NSTEP * 16;
+    static_assert(TH % WAVES == 0 && TW % 16 == 0 && MT % 16 == 0, "tile shape");
+    static_assert(W_STEP_BYTES % (THREADS * 16) == 0, "weight steps are whole DMA rounds");
+    static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+};
+
+// EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD); outputs other than the head are split.
+template <class C, int EPI>
+__global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
+    constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned* lds_tab = reinterpret_cast<unsigned*>(lds + C::OFF_TAB);
+    unsigned* lds_slot = reinterpret_cast<unsigned*>(lds + C::OFF_SLOT);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // XCD-aware tile order (see conv_mfma.h)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_swizzle) {
+        const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+        const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        bx = (int)(wgid % gridDim.x);
+        by = (int)(wgid / gridDim.x);
+    }
+    const int y0 = (by / D) * (C::TH * D) + (by % D);
+    const int x0 = bx * C::TW;
+    const int ybase = y0 - a.pad, xbase = x0 - a.pad;
+
+    constexpr unsigned OOB = 0xffffffffu;
+    // ---- one-time tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell
+    if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
+#pragma unroll 1
+    for (int i = 0; i < C::NR; ++i) {
+        const int g = i * C::THREADS + tid;
+        if (g < C::NPC) {
+            const int c = g / C::CELL_STRIDE;
+            const int rem = g - c * C::CELL_STRIDE;
+            const int r = rem / C::ITW, x = rem - r * C::ITW;
+            const int gy = ybase + r * D, gx = xbase + x;
+            unsigned off = OOB;
+            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win)
+                off = (unsigned)((((size_t)c * a.Hin + gy) * a.Win + gx) * 16);
+            lds_tab[g] = off;
+        }
+    }
+    const size_t plane_in = (size_t)a.cells_in * a.Hin * a.Win;       // cells per input plane
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
+    const void* zsrc = uniform_ptr(a.zeros);
+
+    // round r of the input tile of chunk ch -> input buffer buf (both planes)
+    auto issue_input = [&](int ch, int buf, int r) {
+        const int g = r * C::THREADS + tid;
+        if (g < C::NPC) {
+            const uint4* chunk = a.in + (size_t)ch * C::CC * a.Hin * a.Win;
+            const void* bhi = uniform_ptr(chunk);
+            const void* blo = uniform_ptr(chunk + plane_in);
+            unsigned off = lds_tab[g];
+            if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
+            if (!__any(off == OOB)) {
+                glds_b128(off, bhi, dst);
+                glds_b128(off, blo, dst + C::PLANE_BYTES);
+            } else {
+                if (off != OOB) {
+                    glds_b128(off, bhi, dst);
+                    glds_b128(off, blo, dst + C::PLANE_BYTES);
+                } else {
+                    glds_b128(0u, zsrc, dst);
+                    glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
+                }
+            }
+        }
+    };
+    auto issue_weights = [&](const unsigned char* wcog, int st, int buf) {
+        const void* base = uniform_ptr(wcog + (size_t)st * C::W_STEP_BYTES);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STEP_BYTES + wave * 1024));
+#pragma unroll
+        for (int i = 0; i < C::WR; ++i) glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
+    };
+
+    // per-lane LDS read bases (bytes)
+    const unsigned b_lane = (unsigned)(((wave * C::RPW) * C::ITW + l15) * 16);
+    const unsigned a_lane = (unsigned)(C::OFF_W + lane * 16);
+
+    float hsum[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
+    bool big = false;
+
+    const int n_stages = a.n_chunks * C::NSTEP;
+    const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
+
+    for (int cg = 0; cg < a.cog_inner; ++cg) {
+        const int cog = blockIdx.z * a.cog_inner + cg;
+        const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)cog * w_cog_bytes;
+        f32x4 acc[MW][NW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        __syncthreads();                       // tables written / previous co-group done with the buffers
+#pragma unroll 1
+        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r);
+        issue_weights(wcog, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+#pragma unroll 1
+        for (int s = 0; s < n_stages; ++s) {
+            const int ch = s / C::NSTEP;
+            const int j = s - ch * C::NSTEP;
+            // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
+            if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1);
+            if (ch + 1 < a.n_chunks) {
+#pragma unroll 1
+                for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r);
+            }
+            // ---- the step's MFMAs
+            const unsigned char* bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[j * 4 + l4];
+            const unsigned char* al = lds + a_lane + (s & 1) * C::W_STEP_BYTES;
+            f16x8 bh[NW], bo[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const int off = ((n / NFC) * C::ITW + (n % NFC) * 16) * 16;
+                bh[n] = *reinterpret_cast<const f16x8*>(bl + off);
+                bo[n] = *reinterpret_cast<const f16x8*>(bl + off + C::PLANE_BYTES);
+            }
+            f16x8 ah[2], ao[2];
+            ah[0] = *reinterpret_cast<const f16x8*>(al);
+            ao[0] = *reinterpret_cast<const f16x8*>(al + MW * 1024);
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                if (m + 1 < MW) {
+                    ah[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
+                    ao[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (MW + m + 1) * 1024);
+                }
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bo[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao[m & 1], bh[n], acc[m][n], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next step has landed
+            __syncthreads();
+        }
+
+        // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store
+        const size_t plane_out = (size_t)a.cells_out * a.Hout * a.Wout;
+        const size_t plane_res = (size_t)a.cells_out * a.Hres * a.Wres;
+        const bool has_bias = a.bias != nullptr;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int trow = wave * C::RPW + n / NFC;
+            const int oy = y0 + trow * D;
+            const int ox = x0 + (n % NFC) * 16 + l15;
+            if (oy < a.Hout && ox < a.Wout) {
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    const int co0 = cog * C::MT + m * 16 + l4 * 4;        // 4 consecutive channels: half a cell
+                    const int cell = co0 >> 3, half = (co0 >> 2) & 1;
+                    float v[4];
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) {
+                        if (cell < a.cells_out) {
+                            const size_t rc = ((size_t)cell * a.Hres + (oy + a.res_crop)) * a.Wres + (ox + a.res_crop);
+                            const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
+                            join4(rp[0], rp[plane_res * 2], rv);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + r;
+                        const int cc = co < a.Cout ? co : a.Cout - 1;
+                        v[r] = acc[m][n][r] * a.wscale[cc] + (has_bias ? a.bias[cc] : 0.f);
+                        if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) v[r] += rv[r];
+                        if constexpr (EPI == EPI_RES_POST) v[r] = v[r] * a.post_scale[cc] + a.post_shift[cc];
+                        v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+                        if (co >= a.Cout) v[r] = 0.f;
+                        if constexpr (EPI == EPI_HEAD) v[r] *= a.head_w[cc];
+                    }
+                    if constexpr (EPI == EPI_HEAD) {
+                        hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
+                        if (cell < a.cells_out) {
+                            uint2 hi, lo;
+                            split4(v, hi, lo);
+                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hout + oy) * a.Wout + ox) + half;
+                            op[0] = hi;
+                            op[plane_out * 2] = lo;
+                        }
+                    }
+                }
+            }
+        }
+    }  // co-group loop
+
+    if constexpr (EPI == EPI_HEAD) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            const int trow = wave * C::RPW + n / NFC;
+            const int oy = y0 + trow * D;
+            const int ox = x0 + (n % NFC) * 16 + l15;
+            float h = hsum[n];
+            h += __shfl_xor(h, 16, 64);
+            h += __shfl_xor(h, 32, 64);
+            if (l4 == 0 && oy < a.Hout && ox < a.Wout) a.head_out[(size_t)oy * a.Wout + ox] = h + a.head_b;
+        }
+    } else {
+        if (__any(big) && lane == 0) atomicOr(a.flag, 1u);
+    }
+}
+
+}  // namespace tpz

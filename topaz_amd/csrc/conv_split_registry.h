@@ -1,0 +1,59 @@
+// Registry of compiled conv_split_kernel instantiations (conv_split_inst_*.hip register at load time).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_split.h"
+#include "conv_registry.h"
+
+namespace tpz {
+
+struct SplitKernelInfo {
+    int K, D, MT, epi;
+    int TH, TW, CC, NSTEP, W_STEP_BYTES, lds_bytes;
+    SplitSlot (*slot)(int step, int kb);
+    hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
+    char name[160];
+};
+
+void register_split(const SplitKernelInfo& info);
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi);
+
+template <class C, int EPI>
+hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+template <class C>
+SplitSlot split_slot_of(int step, int kb) { return C::slot(step, kb); }
+
+template <class C, int EPI>
+struct SplitRegistrar {
+    SplitRegistrar() {
+        SplitKernelInfo i;
+        i.K = C::K; i.D = C::D; i.MT = C::MT; i.epi = EPI;
+        i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
+        i.lds_bytes = C::LDS_BYTES;
+        i.slot = &split_slot_of<C>;
+        i.launch = &launch_split_cfg<C, EPI>;
+        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,EPI=%d>", i.K, i.D, i.MT,
+                 i.TH, i.TW, i.CC, i.epi);
+        register_split(i);
+    }
+};
+
+#define TPZ_SPLIT(K, D, MT, TH, TW, CC, EPI) \
+    static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+// ResidA layers: plain (conv0), residual and residual + eval-BN (conv1)
+#define TPZ_SPLIT_RESID(K, D, MT, TH, TW, CC)        \
+    TPZ_SPLIT(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \
+    TPZ_SPLIT(K, D, MT, TH, TW, CC, ::tpz::EPI_RES)   \
+    TPZ_SPLIT(K, D, MT, TH, TW, CC, ::tpz::EPI_RES_POST)
+
+}  // namespace tpz

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "conv_mfma.h"
 #include "kernels_misc.h"
+#include "split_fmt.h"
 
 namespace tpz {
 
@@ -311,6 +312,65 @@ hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* d
     if (n == 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(copy_box_kernel, dim3(blocks), dim3(256), 0, s, src, sps, spitch, dst, dps, dpitch, bd, bh, bw);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 [C][H][W]  <->  split cells (split_fmt.h).  Interop / test helpers of the 2xf16 path: inside a
+// network the conversions are fused into the producing kernels' epilogues.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, int C,
+                                                       size_t hw, unsigned* flag) {
+    bool big = false;
+    const size_t cells = split_cells(C);
+    const size_t n = cells * hw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / hw, px = i - cell * hw;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t c = cell * 8 + j;
+            v[j] = c < (size_t)C ? in[c * hw + px] : 0.f;
+            big |= !(fabsf(v[j]) <= SPLIT_MAX);
+        }
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        uint2 h0, l0, h1, l1;
+        split4(a, h0, l0);
+        split4(b, h1, l1);
+        out[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[n + i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    if (big && flag) atomicOr(flag, 1u);
+}
+
+__global__ __launch_bounds__(256) void from_split_kernel(const uint4* __restrict__ in, float* __restrict__ out, int C,
+                                                         size_t hw) {
+    const size_t cells = split_cells(C);
+    const size_t n = cells * hw;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / hw, px = i - cell * hw;
+        const uint4 h = in[i], l = in[n + i];
+        float a[4], b[4];
+        join4(make_uint2(h.x, h.y), make_uint2(l.x, l.y), a);
+        join4(make_uint2(h.z, h.w), make_uint2(l.z, l.w), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t c = cell * 8 + j;
+            if (c < (size_t)C) out[c * hw + px] = j < 4 ? a[j] : b[j - 4];
+        }
+    }
+}
+
+hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsigned* flag, hipStream_t s) {
+    const size_t n = split_cells(C) * (size_t)H * W;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(to_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, C, (size_t)H * W, flag);
+    return hipGetLastError();
+}
+hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hipStream_t s) {
+    const size_t n = split_cells(C) * (size_t)H * W;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(from_split_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, out, C, (size_t)H * W);
     return hipGetLastError();
 }
 

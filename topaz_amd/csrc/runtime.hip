@@ -11,6 +11,7 @@
 
 #include "../../include/topaz_hip.h"
 #include "conv_registry.h"
+#include "conv_split_registry.h"
 #include "kernels_misc.h"
 
 using namespace tpz;
@@ -29,6 +30,16 @@ const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1, int e
         if (k.dims == dims && k.K == K && k.D == D && k.MT == MT && k.cin1 == (cin1 ? 1 : 0) && k.epi == epi) return &k;
     return nullptr;
 }
+static std::vector<SplitKernelInfo>& split_registry() {
+    static std::vector<SplitKernelInfo> r;
+    return r;
+}
+void register_split(const SplitKernelInfo& info) { split_registry().push_back(info); }
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi) {
+    for (const auto& k : split_registry())
+        if (k.K == K && k.D == D && k.MT == MT && k.epi == epi) return &k;
+    return nullptr;
+}
 }  // namespace tpz
 
 // ------------------------------------------------------------------------------------------------
@@ -37,12 +48,14 @@ const ConvKernelInfo* find_conv(int dims, int K, int D, int MT, bool cin1, int e
 static std::string g_last_error;
 // TPZ_NO_PHASE=1 keeps the fused upsample+concat loader for every decoder layer (A/B switch for tests and tuning)
 static const bool g_no_phase = getenv("TPZ_NO_PHASE") != nullptr;
+// TPZ_EXACT_FP32=1 keeps every network on the fp32 MFMA kernels (the 2xf16 path of conv_split.h is never taken)
+static const bool g_exact_fp32 = getenv("TPZ_EXACT_FP32") != nullptr;
 
 struct ProfRec {
     int cls;
     hipEvent_t e0, e1;
     double flops;
-    const void* key;      // identity of the kernel instantiation (ConvKernelInfo*), nullptr for the rest
+    const void* key;      // identity of the kernel instantiation (its registry name), nullptr for the rest
 };
 struct ProfAcc {
     double ms = 0, flops = 0;
@@ -65,6 +78,9 @@ struct tpz_ctx {
     int nrm_next = 0;
     unsigned int* d_counters = nullptr;
     float* d_zeros = nullptr;     // 256 B of zeros: DMA source of padded / out-of-image elements
+    unsigned* d_flag = nullptr;   // f16-range overflow flag of the 2xf16 path
+    unsigned* h_flag = nullptr;   // pinned copy
+    bool exact = g_exact_fp32;    // fp32 kernels only
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -191,6 +207,12 @@ struct LayerRT {
     float* d_post_shift = nullptr;
     float* d_head_w = nullptr;
     float head_b = 0.f;
+    // 2xf16 path (prepare_split): kernel, packed hi/lo weights, per-channel 2^-s; or the stem that feeds it
+    const SplitKernelInfo* ks = nullptr;
+    const ConvKernelInfo* ki_stem_split = nullptr;
+    void* d_wsplit = nullptr;
+    float* d_wscale = nullptr;
+    int s_n_cog = 1, s_n_chunks = 1;
     // phase decomposition (prepare_phases): the first source arrives 2x nearest-upsampled
     struct Phase {
         bool valid = false;
@@ -209,6 +231,8 @@ struct tpz_model {
     int n_slots = 0;
     std::vector<int> last_use;
     std::vector<void*> dev_allocs;
+    bool split_ok = false;                // every layer has a 2xf16 kernel (or is the stem feeding them)
+    long long n_split = 0, n_fallback = 0;
 };
 
 struct Slot {
@@ -218,6 +242,7 @@ struct Slot {
     int pitch = 0;
     bool owned = false;
     bool set = false;
+    bool split = false;       // p holds split f16 cells (split_fmt.h) instead of fp32 planes
 };
 
 static void set_dense(Slot& s, float* p, int C, int D, int H, int W) {
@@ -405,6 +430,108 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
     return 0;
 }
 
+// ---- 2xf16 path (conv_split.h) ---------------------------------------------------------------------
+// weights [cout][cin][k][k] -> per (co-group, chunk, step) blocks  [plane hi|lo][m][lane = kb*16 + i][8 channels]
+// of f16, scaled per output channel by 2^s (max |w| lands in [2^13, 2^14)) so that the lo halves stay normal.
+static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int cout, int cin, int n_cog, int n_chunks,
+                               std::vector<uint16_t>& out, std::vector<float>& wscale_inv) {
+    const int K = ki.K, MW = ki.MT / 16;
+    const size_t taps = (size_t)K * K;
+    std::vector<float> scale(cout, 1.f);
+    wscale_inv.assign(cout, 1.f);
+    for (int co = 0; co < cout; ++co) {
+        float mx = 0.f;
+        for (size_t i = 0; i < (size_t)cin * taps; ++i) mx = std::max(mx, std::fabs(w[(size_t)co * cin * taps + i]));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) e = std::min(60, std::max(-60, (int)std::floor(std::log2(16384.0 / mx))));
+        scale[co] = std::ldexp(1.f, e);
+        wscale_inv[co] = std::ldexp(1.f, -e);
+    }
+    const size_t step_halfs = (size_t)ki.W_STEP_BYTES / 2;
+    out.assign((size_t)n_cog * n_chunks * ki.NSTEP * step_halfs, 0);
+    for (int cog = 0; cog < n_cog; ++cog)
+        for (int ch = 0; ch < n_chunks; ++ch)
+            for (int step = 0; step < ki.NSTEP; ++step) {
+                uint16_t* blk = out.data() + (((size_t)cog * n_chunks + ch) * ki.NSTEP + step) * step_halfs;
+                for (int kb = 0; kb < 4; ++kb) {
+                    const SplitSlot sl = ki.slot(step, kb);
+                    if (sl.ky < 0) continue;
+                    for (int m = 0; m < MW; ++m)
+                        for (int i = 0; i < 16; ++i) {
+                            const int co = cog * ki.MT + m * 16 + i;
+                            if (co >= cout) continue;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ci = (ch * ki.CC + sl.c) * 8 + j;
+                                if (ci >= cin) continue;
+                                const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * K + sl.kx] * scale[co];
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                uint16_t hb, lb;
+                                memcpy(&hb, &hi, 2);
+                                memcpy(&lb, &lo, 2);
+                                const size_t lane = (size_t)kb * 16 + i;
+                                blk[((size_t)(0 * MW + m) * 64 + lane) * 8 + j] = hb;
+                                blk[((size_t)(1 * MW + m) * 64 + lane) * 8 + j] = lb;
+                            }
+                        }
+                }
+            }
+}
+
+static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi) {
+    const SplitKernelInfo* best = nullptr;
+    int best_padded = 1 << 30;
+    for (int mt : MT_CHOICES) {
+        const SplitKernelInfo* c = find_split(k, dil, mt, epi);
+        if (!c) continue;
+        const int padded = (cout + mt - 1) / mt * mt;
+        if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
+            best = c;
+            best_padded = padded;
+        }
+    }
+    return best;
+}
+
+// Decides whether the whole program can run on the 2xf16 path and prepares it: layer 0 must be a 1-channel stem
+// whose MFMA kernel has a split-storing twin, every other layer a single-source 2-D conv with a split kernel,
+// the last one with the fused head (its scores leave as fp32).  Anything else keeps the model on fp32.
+static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
+    const int nl = (int)m->layers.size();
+    if (nl < 2) return 0;
+    for (int i = 0; i < nl; ++i) {
+        LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        if (L.op != TPZ_OP_CONV || L.dims != 2 || L.src2 >= 0) return 0;
+        if (i == 0) {
+            if (!rt.ki || !rt.ki->cin1 || L.res >= 0 || L.head || L.post_scale_off >= 0 || rt.n_cog != 1) return 0;
+            rt.ki_stem_split = find_conv(2, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
+            if (!rt.ki_stem_split) return 0;
+            continue;
+        }
+        if (!rt.ki || rt.ki->cin1) return 0;
+        if (L.head != (i == nl - 1 ? 1 : 0)) return 0;
+        rt.ks = pick_split(L.k, L.dil, L.cout, rt.ki->epi);
+        if (!rt.ks) return 0;
+    }
+    for (int i = 1; i < nl; ++i) {
+        LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        const SplitKernelInfo& ks = *rt.ks;
+        rt.s_n_cog = (L.cout + ks.MT - 1) / ks.MT;
+        rt.s_n_chunks = (int)((split_cells(L.cin) + ks.CC - 1) / ks.CC);
+        std::vector<uint16_t> packed;
+        std::vector<float> inv;
+        pack_weights_split(ks, blob + L.w_off, L.cout, L.cin, rt.s_n_cog, rt.s_n_chunks, packed, inv);
+        float* d = nullptr;
+        if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
+        rt.d_wsplit = d;
+        if (upload(ctx, m, inv.data(), inv.size(), &rt.d_wscale)) return 1;
+    }
+    m->split_ok = true;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // executor
 // ------------------------------------------------------------------------------------------------
@@ -423,7 +550,7 @@ static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int 
     }
     if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
     dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, n_cog / a.cog_inner);
-    prof_begin(ctx, 0, flops, &ki);
+    prof_begin(ctx, 0, flops, ki.name);
     hipError_t e = ki.launch(a, grid, ctx->stream);
     prof_end(ctx);
     HIPCHK(ctx, e);
@@ -473,8 +600,50 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
     return launch_mfma(ctx, *ph.ki_skip, a, ph.n_cog_skip, fl);
 }
 
+// one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
+static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst) {
+    const tpz_layer& L = rt.L;
+    const SplitKernelInfo& ks = *rt.ks;
+    SplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const uint4*>(s1.p);
+    a.wpk = reinterpret_cast<const uint4*>(rt.d_wsplit);
+    a.wscale = rt.d_wscale;
+    a.bias = rt.d_bias;
+    a.res = sres ? reinterpret_cast<const uint4*>(sres->p) : nullptr;
+    a.post_scale = rt.d_post_scale;
+    a.post_shift = rt.d_post_shift;
+    a.head_w = rt.d_head_w;
+    a.head_b = rt.head_b;
+    if (L.head) a.head_out = dst.p;
+    else a.out = reinterpret_cast<uint4*>(dst.p);
+    a.zeros = ctx->d_zeros;
+    a.flag = ctx->d_flag;
+    a.slope = L.slope;
+    a.cells_in = (int)split_cells(s1.C);
+    a.Hin = s1.H; a.Win = s1.W;
+    a.Cout = L.cout;
+    a.cells_out = (int)split_cells(L.cout);
+    a.Hout = dst.H; a.Wout = dst.W;
+    a.pad = L.pad;
+    if (sres) { a.Hres = sres->H; a.Wres = sres->W; a.res_crop = L.res_crop; }
+    a.n_chunks = rt.s_n_chunks;
+    a.cog_inner = L.head ? rt.s_n_cog : 1;
+    a.tiles_x = (dst.W + ks.TW - 1) / ks.TW;
+    a.tiles_y = (dst.H + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
+    a.xcd_swizzle = 1;
+    if (a.tiles_y > 65535) return fail(ctx, "conv grid too large");
+    dim3 grid(a.tiles_x, a.tiles_y, rt.s_n_cog / a.cog_inner);
+    const double flops = 2.0 * L.cout * L.cin * (double)L.k * L.k * (double)dst.H * dst.W;
+    prof_begin(ctx, 0, flops, ks.name);
+    hipError_t e = ks.launch(a, grid, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
 static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* s2, const Slot* sres, Slot& dst,
-                    const float* d_nrm, int norm_out) {
+                    const float* d_nrm, int norm_out, bool split_out = false) {
     const tpz_layer& L = rt.L;
     ConvArgs a;
     memset(&a, 0, sizeof a);
@@ -509,7 +678,8 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     else a.out = dst.p;
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
     if (rt.ki) {
-        const ConvKernelInfo& ki = *rt.ki;
+        const ConvKernelInfo& ki = split_out ? *rt.ki_stem_split : *rt.ki;    // same tile and weight packing
+        a.flag = ctx->d_flag;
         const LayerRT::Phase& ph = rt.phase;
         if (ph.valid && s2 && s1.C == ph.c1 && s2->C == ph.c2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W &&
             (L.dims == 2 || s2->D == 2 * s1.D))
@@ -532,7 +702,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
 // runs the layer program.  `slots` holds preset external slots (at least slot 0); the dst of the last
 // layer is written to d_out (dense).  d_nrm != nullptr: slot 0 is normalised on load wherever it is read
 // and the output is un-normalised (Denoise._denoise, topaz/denoise.py:283-295).
-static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, const float* d_nrm) {
+static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, const float* d_nrm, bool split = false) {
     tpz_ctx* ctx = m->ctx;
     const int nl = (int)m->layers.size();
     slots.resize(std::max<size_t>(slots.size(), (size_t)m->n_slots));
@@ -557,16 +727,25 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             const int Ho = geo.H + 2 * L.pad - span, Wo = geo.W + 2 * L.pad - span;
             if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input %dx%dx%d too small", i, geo.D, geo.H, geo.W); break; }
             const int Co = L.head ? 1 : L.cout;
-            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, (size_t)Co * Do * Ho * Wo * sizeof(float));
+            // split tensors take the bytes of fp32 with the channels rounded up to whole 8-channel cells
+            const bool split_dst = split && !L.head;
+            const size_t c_alloc = split_dst ? split_cells(Co) * 8 : (size_t)Co;
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
             if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
             set_dense(dst, p, Co, Do, Ho, Wo);
+            dst.split = split_dst;
             dst.owned = (i != nl - 1);
             if (sres && (sres->H - 2 * L.res_crop != Ho || sres->W - 2 * L.res_crop != Wo || sres->C != L.cout)) {
                 rc = fail(ctx, "layer %d: residual geometry mismatch", i);
                 break;
             }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
-            rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
+            if (split && rt.ks) {
+                if (!s1.split || (sres && !sres->split)) { rc = fail(ctx, "layer %d: 2xf16 kernel fed an fp32 tensor", i); break; }
+                rc = run_conv_split(ctx, rt, s1, sres, dst);
+            } else {
+                rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0, split && rt.ki_stem_split);
+            }
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
             const int Do = L.dims == 3 ? s1.D / 2 : 1, Ho = s1.H / 2, Wo = s1.W / 2;
@@ -626,6 +805,7 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
     if (hipMalloc((void**)&ctx->d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_flag, 16) != hipSuccess || hipHostMalloc((void**)&ctx->h_flag, 16) != hipSuccess ||
         hipMalloc((void**)&ctx->d_zeros, 256) != hipSuccess || hipMemset(ctx->d_zeros, 0, 256) != hipSuccess) {
         delete ctx;
         return fail(nullptr, "tpz_ctx_create: hipMalloc failed");
@@ -643,6 +823,8 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipFree(ctx->d_nrm);
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_zeros);
+    (void)hipFree(ctx->d_flag);
+    (void)hipHostFree(ctx->h_flag);
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -697,6 +879,7 @@ static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const
         if (prepare_layer(ctx, m, L, h_blob, n_floats, m->layers[i], c1, c2)) { tpz_model_free(m); return 1; }
         chan[L.dst] = L.op == TPZ_OP_CONV ? (L.head ? 1 : L.cout) : c1;
     }
+    if (preset_chan.size() == 1 && prepare_split(ctx, m, h_blob)) { tpz_model_free(m); return 1; }
     *out = m;
     return 0;
 }
@@ -752,11 +935,102 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
     int Co = 1;
     tpz_model_out_channels(m, &Co);
     for (int b = 0; b < n; ++b) {
-        std::vector<Slot> slots(m->n_slots);
-        set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
-        if (run_program(m, slots, d_out + (size_t)b * Co * Do * Ho * Wo, nullptr)) return 1;
+        float* out_b = d_out + (size_t)b * Co * Do * Ho * Wo;
+        bool done = false;
+        if (m->split_ok && !ctx->exact) {
+            // 2xf16 path; an activation beyond the f16 range (flag) sends this image to the fp32 kernels instead
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
+            std::vector<Slot> slots(m->n_slots);
+            set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
+            if (run_program(m, slots, out_b, nullptr, true)) return 1;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            done = (*ctx->h_flag == 0);
+            if (done) ++m->n_split; else ++m->n_fallback;
+        }
+        if (!done) {
+            std::vector<Slot> slots(m->n_slots);
+            set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
+            if (run_program(m, slots, out_b, nullptr)) return 1;
+        }
     }
     return 0;
+}
+
+int tpz_ctx_set_exact(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    ctx->exact = (on != 0) || g_exact_fp32;
+    return 0;
+}
+
+int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns) {
+    if (!m) return fail(nullptr, "model is NULL");
+    if (eligible) *eligible = m->split_ok ? 1 : 0;
+    if (split_runs) *split_runs = m->n_split;
+    if (fp32_reruns) *fp32_reruns = m->n_fallback;
+    return 0;
+}
+
+int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, const float* h_w, const float* h_b,
+                      int cout, int k, int dil, int pad, float slope, const float* d_res, int res_crop,
+                      const float* h_post_scale, const float* h_post_shift, const float* h_head_w, float head_b,
+                      float* d_out, int* overflow) {
+    if (!ctx || !d_in || !h_w || !d_out) return fail(ctx, "tpz_conv_split_2d: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int epi = EPI_PLAIN;
+    if (h_head_w) epi = EPI_HEAD;
+    else if (d_res) epi = h_post_scale ? EPI_RES_POST : EPI_RES;
+    LayerRT rt;
+    tpz_layer& L = rt.L;
+    memset(&L, 0, sizeof L);
+    L.op = TPZ_OP_CONV; L.dims = 2; L.cin = cin; L.cout = cout; L.k = k; L.dil = dil; L.pad = pad; L.slope = slope;
+    L.res = d_res ? 1 : -1; L.res_crop = res_crop; L.head = h_head_w ? 1 : 0; L.src2 = -1;
+    rt.ks = pick_split(k, dil, cout, epi);
+    if (!rt.ks) return fail(ctx, "tpz_conv_split_2d: no 2xf16 kernel for k=%d dil=%d cout=%d epi=%d", k, dil, cout, epi);
+    const int span = dil * (k - 1);
+    const int Ho = H + 2 * pad - span, Wo = W + 2 * pad - span;
+    if (Ho < 1 || Wo < 1) return fail(ctx, "tpz_conv_split_2d: input too small");
+    tpz_model tmp;
+    tmp.ctx = ctx;
+    rt.s_n_cog = (cout + rt.ks->MT - 1) / rt.ks->MT;
+    rt.s_n_chunks = (int)((split_cells(cin) + rt.ks->CC - 1) / rt.ks->CC);
+    std::vector<uint16_t> packed;
+    std::vector<float> inv;
+    pack_weights_split(*rt.ks, h_w, cout, cin, rt.s_n_cog, rt.s_n_chunks, packed, inv);
+    float* d = nullptr;
+    int rc = upload(ctx, &tmp, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d);
+    rt.d_wsplit = d;
+    if (!rc) rc = upload(ctx, &tmp, inv.data(), inv.size(), &rt.d_wscale);
+    if (!rc && h_b) rc = upload(ctx, &tmp, h_b, cout, &rt.d_bias);
+    if (!rc && h_post_scale) rc = upload(ctx, &tmp, h_post_scale, cout, &rt.d_post_scale);
+    if (!rc && h_post_shift) rc = upload(ctx, &tmp, h_post_shift, cout, &rt.d_post_shift);
+    if (!rc && h_head_w) { rc = upload(ctx, &tmp, h_head_w, cout, &rt.d_head_w); rt.head_b = head_b; }
+    Slot s1, sres, dst;
+    float *x_s = nullptr, *r_s = nullptr, *y_s = nullptr;
+    const int Hr = Ho + 2 * res_crop, Wr = Wo + 2 * res_crop;
+    if (!rc) {
+        x_s = (float*)pool_alloc(ctx, split_cells(cin) * 8 * (size_t)H * W * 4);
+        y_s = (float*)pool_alloc(ctx, split_cells(cout) * 8 * (size_t)Ho * Wo * 4);
+        if (d_res) r_s = (float*)pool_alloc(ctx, split_cells(cout) * 8 * (size_t)Hr * Wr * 4);
+        if (!x_s || !y_s || (d_res && !r_s)) rc = fail(ctx, "out of device memory");
+    }
+    if (!rc) {
+        (void)hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream);
+        (void)launch_to_split(d_in, x_s, cin, H, W, ctx->d_flag, ctx->stream);
+        set_dense(s1, x_s, cin, 1, H, W); s1.split = true;
+        if (d_res) { (void)launch_to_split(d_res, r_s, cout, Hr, Wr, ctx->d_flag, ctx->stream); set_dense(sres, r_s, cout, 1, Hr, Wr); sres.split = true; }
+        set_dense(dst, L.head ? d_out : y_s, L.head ? 1 : cout, 1, Ho, Wo);
+        rc = run_conv_split(ctx, rt, s1, d_res ? &sres : nullptr, dst);
+        if (!rc && !L.head) (void)launch_from_split(y_s, d_out, cout, Ho, Wo, ctx->stream);
+        (void)hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, "tpz_conv_split_2d: kernel failed");
+        if (overflow) *overflow = (int)*ctx->h_flag;
+    }
+    if (x_s) pool_release(ctx, x_s);
+    if (y_s) pool_release(ctx, y_s);
+    if (r_s) pool_release(ctx, r_s);
+    for (void* p_ : tmp.dev_allocs) (void)hipFree(p_);
+    return rc;
 }
 
 // ---- denoising ---------------------------------------------------------------------------------
@@ -1102,11 +1376,7 @@ int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches,
     if (flops) *flops = acc.flops;
     if (name && name_len > 0) {
         name[0] = 0;
-        if (have) {
-            const ConvKernelInfo* k = (const ConvKernelInfo*)order[rank].first;
-            snprintf(name, name_len, "conv_mfma_kernel<K=%d,D=%d,MT=%d,TD=%d,TH=%d,TW=%d,KG=%d,RPS=%d,CIN1=%d,DIMS=%d,EPI=%d>",
-                     k->K, k->D, k->MT, k->TD, k->TH, k->TW, k->KG, k->RPS, k->cin1, k->dims, k->epi);
-        }
+        if (have) snprintf(name, name_len, "%s", (const char*)order[rank].first);
     }
     return 0;
 }

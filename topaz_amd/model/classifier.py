@@ -87,6 +87,12 @@ class LinearClassifier:
             self._device = ctx.device
         return self
 
+    @property
+    def device_model(self) -> DeviceModel:
+        if self._device_model is None:
+            self.cuda()
+        return self._device_model
+
     def to(self, device):
         d = torch.device(device)
         if d.type != 'cuda':

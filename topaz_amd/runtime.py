@@ -65,6 +65,10 @@ class Context:
     def prof_reset(self) -> None:
         check(self.lib.tpz_prof_reset(self.handle), self.handle)
 
+    def set_exact(self, on: bool = True) -> None:
+        """pin the fp32 MFMA kernels (no 2xf16 path) for models run on this context"""
+        check(self.lib.tpz_ctx_set_exact(self.handle, 1 if on else 0), self.handle)
+
     def prof_get(self, cls: int) -> Tuple[float, int, float]:
         ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
         check(self.lib.tpz_prof_get(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)), self.handle)
@@ -218,6 +222,12 @@ class DeviceModel:
               self.ctx.handle)
         return a.value, b.value, c.value
 
+    def split_stats(self) -> Tuple[bool, int, int]:
+        """(eligible for the 2xf16 path, images finished on it, images re-run on the fp32 kernels)"""
+        e, a, b = C.c_int(), C.c_longlong(), C.c_longlong()
+        check(self.ctx.lib.tpz_model_split_stats(self.handle, C.byref(e), C.byref(a), C.byref(b)), self.ctx.handle)
+        return bool(e.value), a.value, b.value
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [N,1,(D,)H,W] (or without the channel axis) on the ctx device -> [N,1,(Do,)Ho,Wo]"""
         self.ctx.bind_current_stream()
@@ -306,6 +316,41 @@ def conv(x: torch.Tensor, weight, bias=None, dil: int = 1, pad: int = 0, slope: 
                            _ptr(res) if res is not None else C.c_void_p(None), res_crop, ps_, pt, ph, float(head_b),
                            _ptr(y)), ctx.handle)
     return y
+
+
+def conv_split(x: torch.Tensor, weight, bias=None, dil: int = 1, pad: int = 0, slope: float = 1.0,
+               res: Optional[torch.Tensor] = None, res_crop: int = 0, post_scale=None, post_shift=None,
+               head_w=None, head_b: float = 0.0, ctx: Optional[Context] = None) -> Tuple[torch.Tensor, bool]:
+    """The same 2-D convolution on the 2xf16 kernels (tpz_conv_split_2d): fp32 tensors in and out, converted
+    to split f16 cells on the device.  Returns (y, overflow) -- overflow: a result left the f16 range."""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    w = np.ascontiguousarray(np.asarray(weight, dtype=np.float32))
+    x = as_device_f32(x, ctx)
+    cin, H, W = x.shape
+    cout, k = w.shape[0], w.shape[-1]
+    assert w.ndim == 4 and w.shape[1] == cin, (w.shape, cin)
+    span = dil * (k - 1)
+    Ho, Wo = H + 2 * pad - span, W + 2 * pad - span
+    y = torch.empty((1 if head_w is not None else cout, Ho, Wo), dtype=torch.float32, device=x.device)
+
+    def hp(a):
+        if a is None:
+            return None, C.c_void_p(None)
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    kb, pb = hp(bias)
+    ks, ps_ = hp(post_scale)
+    kt, pt = hp(post_shift)
+    kh, ph = hp(head_w)
+    if res is not None:
+        res = as_device_f32(res, ctx)
+    ovf = C.c_int(0)
+    check(ctx.lib.tpz_conv_split_2d(ctx.handle, _ptr(x), cin, H, W, w.ctypes.data_as(C.c_void_p), pb, cout, k, dil,
+                                    pad, float(slope), _ptr(res) if res is not None else C.c_void_p(None), res_crop,
+                                    ps_, pt, ph, float(head_b), _ptr(y), C.byref(ovf)), ctx.handle)
+    return y, bool(ovf.value)
 
 
 def maxpool2(x: torch.Tensor, ctx: Optional[Context] = None) -> torch.Tensor:
