@@ -154,3 +154,43 @@ def test_out_of_range_activations_rerun_in_fp32(gpu_ctx):
     finally:
         gpu_ctx.set_exact(False)
     assert np.array_equal(y, y32), 'the re-run must be the fp32 path itself'
+
+
+@pytest.mark.parametrize('shape', [(256, 320), (253, 190), (150, 140)])
+def test_unet_denoise_on_split_path_matches_oracle(gpu_ctx, shape):
+    """The 48-filter U-Net goes down the 2xf16 path: encoder / decoder 3x3 convs, the per-parity decoder kernels
+    where the skip is exactly 2x the upsampled tensor (all levels for 256x320), fp32 kernels with on-device
+    format conversion where it is not (odd sizes), dec1.2 storing fp32 for the 1-channel last conv."""
+    from oracle import denoising as oden
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)
+    dn = Denoise(DenoiseNet('unet', sd))
+    x = np.random.RandomState(8).randn(*shape).astype(np.float32) * 3 + 1
+    ref = oden.denoise('unet', sd, x)
+    dm = dn.model.device_model
+    before = dm.split_stats()
+    assert before[0], 'the U-Net should be eligible for the 2xf16 path'
+    y = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
+    after = dm.split_stats()
+    assert after[1] == before[1] + 1 and after[2] == before[2]
+    assert _err(y, ref) <= 1e-4
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
+    finally:
+        gpu_ctx.set_exact(False)
+    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+
+
+def test_unet_patched_denoise_split_matches_oracle(gpu_ctx):
+    from oracle import denoising as oden
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(12, nf=48, base_width=11, top_width=5)
+    dn = Denoise(DenoiseNet('unet', sd))
+    x = np.random.RandomState(9).randn(300, 280).astype(np.float32)
+    ref = oden.denoise('unet', sd, x, patch_size=128, padding=64)
+    y = dn.denoise_device(torch.from_numpy(x).cuda(), 128, 64).cpu().numpy()
+    assert _err(y, ref) <= 1e-4
+    assert dn.model.device_model.split_stats()[1] >= 1

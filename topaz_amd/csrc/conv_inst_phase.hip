@@ -8,6 +8,7 @@ TPZ_CONV2D(2, 1, 32, 16, 32, 2, 2, false)
 TPZ_CONV2D(2, 1, 64, 16, 32, 2, 2, false)
 TPZ_CONV2D(2, 1, 96, 8,  32, 2, 2, false)
 TPZ_CONV2D_EPI(5, 1, 64, 16, 32, 1, 5, true, ::tpz::EPI_RES)
+TPZ_CONV2D_EPI(5, 1, 64, 16, 32, 1, 5, true, ::tpz::EPI_SPLIT)     // the same skip-source part, feeding the 2xf16 phases
 TPZ_CONV2D_EPI(3, 1, 64, 16, 32, 1, 3, true, ::tpz::EPI_RES)
 //              K  D  MT  TD TH  TW  KG RPS CIN1   EPI
 TPZ_CONV3D(2, 1, 16, 4, 4, 32, 1, 4, false)

@@ -39,8 +39,9 @@ struct SplitArgs {
     const uint4* wpk;         // packed weights (runtime.hip pack_weights_split)
     const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling
     const float* bias;        // [Cout] or nullptr
-    uint4* out;               // split tensor [2][cells_out][Hout][Wout] (nullptr when the head is fused)
-    const uint4* res;         // split residual [2][cells_out][Hres][Wres] or nullptr
+    uint4* out;               // split tensor [2][cells_out][Hfull][Wfull] (nullptr: fused head / fp32 output)
+    float* out_f32;           // EPI_PLAIN_F32: fp32 planes [Cout][Hfull][Wfull] instead
+    const uint4* res;         // split residual [2][cells_out][Hres][Wres] or nullptr (may alias out: in place)
     const float* post_scale;  // [Cout] affine after the residual add (eval BN) or nullptr
     const float* post_shift;
     const float* head_w;      // fused 1x1 head: [Cout]
@@ -50,7 +51,10 @@ struct SplitArgs {
     float head_b, slope;
     int cells_in, Hin, Win;
     int Cout, cells_out, Hout, Wout;
-    int pad;
+    int pad_x, pad_y;
+    // output lattice as in conv_mfma.h: element (oy, ox) of the launch is element (oy*os + ooy, ox*os + oox)
+    // of the [Hfull][Wfull] output; the residual is read at the same full-tensor position (+ res_crop)
+    int os, ooy, oox, Hfull, Wfull;
     int Hres, Wres, res_crop;
     int n_chunks;             // chunks of CC cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
@@ -104,18 +108,19 @@ struct SplitCfg {
         return (s.c * CELL_STRIDE + s.ky * ITW + s.kx * D) * 16;
     }
     static constexpr int W_STEP_BYTES = 2 * MW * 1024;              // hi + lo A fragments of one step
-    static constexpr int WR = W_STEP_BYTES / (THREADS * 16);        // DMA rounds per weight step
+    static constexpr int WR = (W_STEP_BYTES + THREADS * 16 - 1) / (THREADS * 16);   // DMA rounds per weight step
     static constexpr int OFF_W = 2 * IN_BUF;
     static constexpr int OFF_TAB = OFF_W + 2 * W_STEP_BYTES;
     static constexpr int OFF_SLOT = OFF_TAB + NPC * 4;
     static constexpr int LDS_BYTES = OFF_SLOT + NSTEP * 16;
     static_assert(TH % WAVES == 0 && TW % 16 == 0 && MT % 16 == 0, "tile shape");
-    static_assert(W_STEP_BYTES % (THREADS * 16) == 0, "weight steps are whole DMA rounds");
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
 };
 
-// EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD); outputs other than the head are split.
+// EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
+// EPI_PLAIN_F32 = plain epilogue storing fp32 planes, for a layer whose consumer is not on the 2xf16 path.
+enum { EPI_PLAIN_F32 = 5 };
 template <class C, int EPI>
 __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
     }
     const int y0 = (by / D) * (C::TH * D) + (by % D);
     const int x0 = bx * C::TW;
-    const int ybase = y0 - a.pad, xbase = x0 - a.pad;
+    const int ybase = y0 - a.pad_y, xbase = x0 - a.pad_x;
 
     constexpr unsigned OOB = 0xffffffffu;
     // ---- one-time tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell
@@ -190,7 +195,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
         const void* base = uniform_ptr(wcog + (size_t)st * C::W_STEP_BYTES);
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STEP_BYTES + wave * 1024));
 #pragma unroll
-        for (int i = 0; i < C::WR; ++i) glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
+        for (int i = 0; i < C::WR; ++i)
+            if ((i * C::WAVES + wave) * 1024 < C::W_STEP_BYTES)       // whole waves (1 KiB each)
+                glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
     };
 
     // per-lane LDS read bases (bytes)
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
         }
 
         // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store
-        const size_t plane_out = (size_t)a.cells_out * a.Hout * a.Wout;
+        const size_t plane_out = (size_t)a.cells_out * a.Hfull * a.Wfull;
         const size_t plane_res = (size_t)a.cells_out * a.Hres * a.Wres;
         const bool has_bias = a.bias != nullptr;
 #pragma unroll
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
             const int oy = y0 + trow * D;
             const int ox = x0 + (n % NFC) * 16 + l15;
             if (oy < a.Hout && ox < a.Wout) {
+                const int fy = oy * a.os + a.ooy, fx = ox * a.os + a.oox;     // position in the full output
 #pragma unroll
                 for (int m = 0; m < MW; ++m) {
                     const int co0 = cog * C::MT + m * 16 + l4 * 4;        // 4 consecutive channels: half a cell
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
                     float rv[4] = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) {
                         if (cell < a.cells_out) {
-                            const size_t rc = ((size_t)cell * a.Hres + (oy + a.res_crop)) * a.Wres + (ox + a.res_crop);
+                            const size_t rc = ((size_t)cell * a.Hres + (fy + a.res_crop)) * a.Wres + (fx + a.res_crop);
                             const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
                             join4(rp[0], rp[plane_res * 2], rv);
                         }
@@ -300,13 +308,17 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
                     }
                     if constexpr (EPI == EPI_HEAD) {
                         hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    } else if constexpr (EPI == EPI_PLAIN_F32) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + r < a.Cout) a.out_f32[((size_t)(co0 + r) * a.Hfull + fy) * a.Wfull + fx] = v[r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
                         if (cell < a.cells_out) {
                             uint2 hi, lo;
                             split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hout + oy) * a.Wout + ox) + half;
+                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + fy) * a.Wfull + fx) + half;
                             op[0] = hi;
                             op[plane_out * 2] = lo;
                         }
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
             h += __shfl_xor(h, 32, 64);
             if (l4 == 0 && oy < a.Hout && ox < a.Wout) a.head_out[(size_t)oy * a.Wout + ox] = h + a.head_b;
         }
-    } else {
+    } else if constexpr (EPI != EPI_PLAIN_F32) {
         if (__any(big) && lane == 0) atomicOr(a.flag, 1u);
     }
 }

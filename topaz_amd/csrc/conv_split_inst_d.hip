@@ -1,0 +1,11 @@
+// 2xf16-split kernels of the 2-D U-Net denoisers at 48 base filters (topaz/denoising/models.py:74-175):
+// encoder / decoder 3x3 convs, the per-parity kernels of the decoders' first convs (runtime.hip
+// prepare_phases: 2-tap kernels for k = 3, 3-tap for k = 5, added in place onto the skip-source part),
+// and dec1.2, whose consumer (the 1-channel last conv) reads fp32.
+#include "conv_split_registry.h"
+//         K  D  MT  TH  TW  CC  EPI
+TPZ_SPLIT(3, 1, 48, 16, 32, 2, ::tpz::EPI_PLAIN)
+TPZ_SPLIT(3, 1, 96, 16, 32, 2, ::tpz::EPI_PLAIN)
+TPZ_SPLIT(2, 1, 96, 16, 32, 2, ::tpz::EPI_RES)
+TPZ_SPLIT(3, 1, 64, 16, 32, 2, ::tpz::EPI_RES)
+TPZ_SPLIT(5, 1, 32, 16, 32, 2, ::tpz::EPI_PLAIN_F32)

@@ -164,6 +164,45 @@ hipError_t launch_maxpool2(const float* in, float* out, int C, int D, int H, int
     return hipGetLastError();
 }
 
+// MaxPool2d(2) on split cells: the (hi, lo) pair of the largest of the four values is selected per channel,
+// so the result equals the pooled fp32 value exactly.
+__global__ __launch_bounds__(256) void maxpool2_split_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                             int cells, int H, int W, int Ho, int Wo) {
+    const size_t n = (size_t)cells * Ho * Wo;
+    const size_t plane_in = (size_t)cells * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        const size_t t = i / Wo;
+        const int y = (int)(t % Ho);
+        const size_t c = t / Ho;
+        const size_t p = (c * H + 2 * y) * W + 2 * x;
+        const size_t idx[4] = {p, p + 1, p + W, p + W + 1};
+        f16x8 bh = __builtin_bit_cast(f16x8, in[idx[0]]), bl = __builtin_bit_cast(f16x8, in[plane_in + idx[0]]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const f16x8 h = __builtin_bit_cast(f16x8, in[idx[k]]), l = __builtin_bit_cast(f16x8, in[plane_in + idx[k]]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // hi + lo compares as the fp32 value it stands for
+                const float a = (float)bh[j] + (float)bl[j], b = (float)h[j] + (float)l[j];
+                if (b > a || a != a) { bh[j] = h[j]; bl[j] = l[j]; }   // fmaxf semantics, as maxpool2_kernel
+            }
+        }
+        out[i] = __builtin_bit_cast(uint4, bh);
+        out[n + i] = __builtin_bit_cast(uint4, bl);
+    }
+}
+
+hipError_t launch_maxpool2_split(const void* in, void* out, int C, int H, int W, hipStream_t s) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t n = split_cells(C) * (size_t)Ho * Wo;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool2_split_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, (uint4*)out,
+                       (int)split_cells(C), H, W, Ho, Wo);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // mean / std of a (strided) 3-D box, deterministic two-stage reduction in fp64.
 // Stage 1 writes per-block partial (sum, sumsq); stage 2 (one block) folds them in fixed order

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -213,6 +214,20 @@ struct LayerRT {
     void* d_wsplit = nullptr;
     float* d_wscale = nullptr;
     int s_n_cog = 1, s_n_chunks = 1;
+    // 2xf16 twin of the phase decomposition: the skip-source part runs first (stem kernel storing split cells
+    // when the skip is the 1-channel image, else a plain split kernel), then one split kernel per output parity
+    // adds itself in place through the residual epilogue and applies the activation
+    struct SplitPhase {
+        bool valid = false;
+        const SplitKernelInfo* ks_low = nullptr;       // k1-tap kernel, EPI_RES, lattice output
+        const SplitKernelInfo* ks_skip = nullptr;      // k-tap kernel over a multi-channel skip source, EPI_PLAIN
+        const ConvKernelInfo* ki_skip_stem = nullptr;  // 1-channel skip source: fp32 CIN1 kernel, EPI_SPLIT
+        int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
+        void* d_w_low[4] = {nullptr, nullptr, nullptr, nullptr};
+        float* d_ws_low[4] = {nullptr, nullptr, nullptr, nullptr};
+        void* d_w_skip = nullptr;
+        float* d_ws_skip = nullptr;
+    } sphase;
     // phase decomposition (prepare_phases): the first source arrives 2x nearest-upsampled
     struct Phase {
         bool valid = false;
@@ -243,6 +258,7 @@ struct Slot {
     bool owned = false;
     bool set = false;
     bool split = false;       // p holds split f16 cells (split_fmt.h) instead of fp32 planes
+    float* alt = nullptr;     // the same tensor converted to the other format for a consumer that needs it
 };
 
 static void set_dense(Slot& s, float* p, int C, int D, int H, int W) {
@@ -493,42 +509,133 @@ static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi) {
     return best;
 }
 
-// Decides whether the whole program can run on the 2xf16 path and prepares it: layer 0 must be a 1-channel stem
-// whose MFMA kernel has a split-storing twin, every other layer a single-source 2-D conv with a split kernel,
-// the last one with the fused head (its scores leave as fp32).  Anything else keeps the model on fp32.
+static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInfo& ks, const float* w, int cout, int cin,
+                                int* n_cog, int* n_chunks, void** d_w, float** d_ws) {
+    *n_cog = (cout + ks.MT - 1) / ks.MT;
+    *n_chunks = (int)((split_cells(cin) + ks.CC - 1) / ks.CC);
+    std::vector<uint16_t> packed;
+    std::vector<float> inv;
+    pack_weights_split(ks, w, cout, cin, *n_cog, *n_chunks, packed, inv);
+    float* d = nullptr;
+    if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
+    *d_w = d;
+    return upload(ctx, m, inv.data(), inv.size(), d_ws);
+}
+
+// 2xf16 twin of prepare_phases for a 2-D decoder layer conv(cat(upsample2x(a), b)); needs rt.phase (fp32)
+static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, LayerRT& rt) {
+    const tpz_layer& L = rt.L;
+    const LayerRT::Phase& ph = rt.phase;
+    LayerRT::SplitPhase& sp = rt.sphase;
+    if (!ph.valid || L.dims != 2 || ph.c1 % 8 != 0) return 0;
+    const int k = L.k, k1 = ph.k1, c1 = ph.c1, c2 = ph.c2;
+    sp.ks_low = pick_split(k1, 1, L.cout, EPI_RES);
+    if (!sp.ks_low) return 0;
+    if (c2 == 1) {
+        // same tile and weight packing as the fp32 skip kernel of prepare_phases: its packed weights are reused
+        if (!ph.ki_skip->cin1) return 0;
+        sp.ki_skip_stem = find_conv(2, k, 1, ph.ki_skip->MT, true, EPI_SPLIT);
+        if (!sp.ki_skip_stem || ph.n_cog_skip != 1) return 0;
+    } else {
+        sp.ks_skip = pick_split(k, 1, L.cout, EPI_PLAIN);
+        if (!sp.ks_skip) return 0;
+    }
+    const size_t taps = (size_t)k * k, taps1 = (size_t)k1 * k1;
+    std::vector<double> acc;
+    std::vector<float> eff;
+    for (int p = 0; p < 4; ++p) {
+        const int px = p & 1, py = (p >> 1) & 1;
+        acc.assign((size_t)L.cout * c1 * taps1, 0.0);
+        for (int co = 0; co < L.cout; ++co)
+            for (int ci = 0; ci < c1; ++ci)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx)
+                        acc[((size_t)co * c1 + ci) * taps1 + (size_t)phase_tap(k, py, ky) * k1 + phase_tap(k, px, kx)] +=
+                            (double)w[((size_t)co * L.cin + ci) * taps + (size_t)ky * k + kx];
+        eff.resize(acc.size());
+        for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
+        if (upload_split_weights(ctx, m, *sp.ks_low, eff.data(), L.cout, c1, &sp.n_cog_low, &sp.n_chunks_low,
+                                 &sp.d_w_low[p], &sp.d_ws_low[p])) return 1;
+    }
+    if (sp.ks_skip) {
+        eff.resize((size_t)L.cout * c2 * taps);
+        for (int co = 0; co < L.cout; ++co)
+            for (int ci = 0; ci < c2; ++ci)
+                memcpy(&eff[((size_t)co * c2 + ci) * taps], &w[((size_t)co * L.cin + c1 + ci) * taps], taps * sizeof(float));
+        if (upload_split_weights(ctx, m, *sp.ks_skip, eff.data(), L.cout, c2, &sp.n_cog_skip, &sp.n_chunks_skip,
+                                 &sp.d_w_skip, &sp.d_ws_skip)) return 1;
+    }
+    sp.valid = true;
+    return 0;
+}
+
+// Chooses, layer by layer, what can run on the 2xf16 path (2-D programs only):
+//   * single-source convs with a conv_split kernel for their (k, dilation, cout, epilogue);
+//   * decoder convs over an upsampled + a skip source through the per-parity twin (prepare_split_phases);
+//   * 1-channel stems keep their fp32 MFMA kernel but store split cells when their consumers read them;
+//   * max-pooling runs in whichever format its source has.
+// A conv_split layer whose consumers all read fp32 (the 1-output-channel last conv of the U-Nets runs on the
+// direct kernel) takes the fp32-storing variant when one is compiled; everything else that meets a tensor in the
+// other format has it converted on the device (run_program / slot_as).
 static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
     const int nl = (int)m->layers.size();
-    if (nl < 2) return 0;
+    for (auto& rt : m->layers)
+        if (rt.L.dims != 2) return 0;
+    // does layer j read slot `slot` as split cells?  (max-pool: whatever its own consumers read)
+    std::vector<int> reads(nl, 0);              // per conv layer: 1 = its (non-image) sources are read as split
     for (int i = 0; i < nl; ++i) {
         LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        if (L.op != TPZ_OP_CONV || L.dims != 2 || L.src2 >= 0) return 0;
-        if (i == 0) {
-            if (!rt.ki || !rt.ki->cin1 || L.res >= 0 || L.head || L.post_scale_off >= 0 || rt.n_cog != 1) return 0;
-            rt.ki_stem_split = find_conv(2, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
-            if (!rt.ki_stem_split) return 0;
+        if (L.op != TPZ_OP_CONV || !rt.ki || rt.ki->cin1) continue;
+        if (L.src2 >= 0) {
+            if (prepare_split_phases(ctx, m, blob + L.w_off, rt)) return 1;
+            reads[i] = rt.sphase.valid ? 1 : 0;
             continue;
         }
-        if (!rt.ki || rt.ki->cin1) return 0;
-        if (L.head != (i == nl - 1 ? 1 : 0)) return 0;
         rt.ks = pick_split(L.k, L.dil, L.cout, rt.ki->epi);
-        if (!rt.ks) return 0;
+        if (!rt.ks && rt.ki->epi == EPI_PLAIN) rt.ks = pick_split(L.k, L.dil, L.cout, EPI_PLAIN_F32);
+        reads[i] = rt.ks ? 1 : 0;
     }
-    for (int i = 1; i < nl; ++i) {
+    std::function<bool(int)> slot_read_split = [&](int slot) {
+        bool any = false;
+        for (int j = 0; j < nl; ++j) {
+            const tpz_layer& Lj = m->layers[j].L;
+            const bool uses = Lj.src == slot || Lj.src2 == slot || Lj.res == slot;
+            if (!uses) continue;
+            if (Lj.op == TPZ_OP_MAXPOOL2) any |= slot_read_split(Lj.dst);
+            else if (Lj.src2 == slot && m->layers[j].sphase.valid && m->layers[j].sphase.ki_skip_stem) continue;  // fp32
+            else any |= reads[j] != 0;
+        }
+        return any;
+    };
+    bool any_split = false;
+    for (int i = 0; i < nl; ++i) {
         LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        const SplitKernelInfo& ks = *rt.ks;
-        rt.s_n_cog = (L.cout + ks.MT - 1) / ks.MT;
-        rt.s_n_chunks = (int)((split_cells(L.cin) + ks.CC - 1) / ks.CC);
-        std::vector<uint16_t> packed;
-        std::vector<float> inv;
-        pack_weights_split(ks, blob + L.w_off, L.cout, L.cin, rt.s_n_cog, rt.s_n_chunks, packed, inv);
-        float* d = nullptr;
-        if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
-        rt.d_wsplit = d;
-        if (upload(ctx, m, inv.data(), inv.size(), &rt.d_wscale)) return 1;
+        if (L.op != TPZ_OP_CONV) continue;
+        const bool wanted = slot_read_split(L.dst);
+        if (rt.ki && rt.ki->cin1 && L.src2 < 0) {
+            // stem: fp32 MFMA kernel, split store when the consumers read split cells
+            if (wanted && L.res < 0 && !L.head && L.post_scale_off < 0 && rt.n_cog == 1)
+                rt.ki_stem_split = find_conv(2, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
+            continue;
+        }
+        if (rt.ks) {
+            if (!L.head && !wanted && rt.ks->epi == EPI_PLAIN) {
+                const SplitKernelInfo* f = find_split(L.k, L.dil, rt.ks->MT, EPI_PLAIN_F32);
+                if (!f) f = pick_split(L.k, L.dil, L.cout, EPI_PLAIN_F32);
+                if (f) rt.ks = f;
+            }
+            if (i == nl - 1 && !L.head && rt.ks->epi != EPI_PLAIN_F32) rt.ks = nullptr;    // the result leaves as fp32
+        }
+        if (rt.ks) {
+            if (upload_split_weights(ctx, m, *rt.ks, blob + L.w_off, L.cout, L.cin, &rt.s_n_cog, &rt.s_n_chunks,
+                                     &rt.d_wsplit, &rt.d_wscale)) return 1;
+            any_split = true;
+        }
+        if (rt.sphase.valid) any_split = true;
     }
-    m->split_ok = true;
+    m->split_ok = any_split;
     return 0;
 }
 
@@ -616,6 +723,7 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.head_w = rt.d_head_w;
     a.head_b = rt.head_b;
     if (L.head) a.head_out = dst.p;
+    else if (ks.epi == EPI_PLAIN_F32) a.out_f32 = dst.p;
     else a.out = reinterpret_cast<uint4*>(dst.p);
     a.zeros = ctx->d_zeros;
     a.flag = ctx->d_flag;
@@ -625,7 +733,9 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.Cout = L.cout;
     a.cells_out = (int)split_cells(L.cout);
     a.Hout = dst.H; a.Wout = dst.W;
-    a.pad = L.pad;
+    a.pad_x = a.pad_y = L.pad;
+    a.os = 1;
+    a.Hfull = dst.H; a.Wfull = dst.W;
     if (sres) { a.Hres = sres->H; a.Wres = sres->W; a.res_crop = L.res_crop; }
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = L.head ? rt.s_n_cog : 1;
@@ -640,6 +750,116 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     prof_end(ctx);
     HIPCHK(ctx, e);
     return 0;
+}
+
+static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops) {
+    a.tiles_x = (a.Wout + ks.TW - 1) / ks.TW;
+    a.tiles_y = (a.Hout + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
+    a.xcd_swizzle = 1;
+    if (a.tiles_y > 65535) return fail(ctx, "conv grid too large");
+    dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
+    prof_begin(ctx, 0, flops, ks.name);
+    hipError_t e = ks.launch(a, grid, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+// conv(cat(upsample2x(s1), s2)) on the 2xf16 path (prepare_split_phases).  s1: split; s2: fp32 when it is the
+// 1-channel image (stem kernel), else split; dst: split.
+static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot& s2, Slot& dst) {
+    const tpz_layer& L = rt.L;
+    const LayerRT::SplitPhase& sp = rt.sphase;
+    const LayerRT::Phase& ph = rt.phase;
+    // ---- skip-source part over the full grid: bias, no activation
+    if (sp.ki_skip_stem) {
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = s2.p;
+        a.wpk = ph.d_w_skip;
+        a.bias = rt.d_bias;
+        a.out = dst.p;
+        a.zeros = ctx->d_zeros;
+        a.flag = ctx->d_flag;
+        a.Cin = a.Cin1 = 1;
+        a.Din = a.D1 = 1; a.Hin = a.H1 = s2.H; a.Win = a.W1 = s2.W;
+        a.cs1 = s2.cs; a.ps1 = s2.ps; a.pitch1 = s2.pitch;
+        a.Cout = L.cout;
+        a.Dout = 1; a.Hout = dst.H; a.Wout = dst.W;
+        a.pad = a.pad_x = a.pad_y = a.pad_z = L.pad;
+        a.os = 1;
+        a.Dfull = 1; a.Hfull = dst.H; a.Wfull = dst.W;
+        a.slope = 1.f;
+        a.n_chunks = 1;
+        a.cog_inner = 1;
+        const double fl = 2.0 * L.cout * (double)L.k * L.k * (double)dst.H * dst.W;
+        if (launch_mfma(ctx, *sp.ki_skip_stem, a, 1, fl)) return 1;
+    } else {
+        SplitArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = reinterpret_cast<const uint4*>(s2.p);
+        a.wpk = reinterpret_cast<const uint4*>(sp.d_w_skip);
+        a.wscale = sp.d_ws_skip;
+        a.bias = rt.d_bias;
+        a.out = reinterpret_cast<uint4*>(dst.p);
+        a.zeros = ctx->d_zeros;
+        a.flag = ctx->d_flag;
+        a.slope = 1.f;
+        a.cells_in = (int)split_cells(s2.C);
+        a.Hin = s2.H; a.Win = s2.W;
+        a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
+        a.Hout = dst.H; a.Wout = dst.W;
+        a.pad_x = a.pad_y = L.pad;
+        a.os = 1; a.Hfull = dst.H; a.Wfull = dst.W;
+        a.n_chunks = sp.n_chunks_skip;
+        a.cog_inner = 1;
+        const double fl = 2.0 * L.cout * ph.c2 * (double)L.k * L.k * (double)dst.H * dst.W;
+        if (launch_split(ctx, *sp.ks_skip, a, sp.n_cog_skip, fl)) return 1;
+    }
+    // ---- one launch per output parity over the low-resolution source, added in place, then the activation
+    for (int p = 0; p < 4; ++p) {
+        const int px = p & 1, py = (p >> 1) & 1;
+        SplitArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = reinterpret_cast<const uint4*>(s1.p);
+        a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low[p]);
+        a.wscale = sp.d_ws_low[p];
+        a.out = reinterpret_cast<uint4*>(dst.p);
+        a.res = reinterpret_cast<const uint4*>(dst.p);
+        a.zeros = ctx->d_zeros;
+        a.flag = ctx->d_flag;
+        a.slope = L.slope;
+        a.cells_in = (int)split_cells(s1.C);
+        a.Hin = s1.H; a.Win = s1.W;
+        a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
+        a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of this parity
+        a.pad_x = phase_pad(L.k, px); a.pad_y = phase_pad(L.k, py);
+        a.os = 2; a.oox = px; a.ooy = py;
+        a.Hfull = dst.H; a.Wfull = dst.W;
+        a.Hres = dst.H; a.Wres = dst.W; a.res_crop = 0;
+        a.n_chunks = sp.n_chunks_low;
+        a.cog_inner = 1;
+        const double fl = 2.0 * L.cout * ph.c1 * (double)ph.k1 * ph.k1 * (double)s1.H * s1.W;
+        if (launch_split(ctx, *sp.ks_low, a, sp.n_cog_low, fl)) return 1;
+    }
+    return 0;
+}
+
+// the slot's 2-D tensor in the wanted format: the producer's own buffer, or a converted copy made once
+static float* slot_as(tpz_ctx* ctx, Slot& s, bool want_split) {
+    if (s.split == want_split) return s.p;
+    if (s.alt) return s.alt;
+    if (s.D != 1 || s.pitch != s.W || s.ps != (long long)s.H * s.W) return nullptr;
+    const size_t c_alloc = want_split ? split_cells(s.C) * 8 : (size_t)s.C;
+    float* q = (float*)pool_alloc(ctx, c_alloc * s.H * s.W * sizeof(float));
+    if (!q) return nullptr;
+    prof_begin(ctx, 2, 0);
+    hipError_t e = want_split ? launch_to_split(s.p, q, s.C, s.H, s.W, ctx->d_flag, ctx->stream)
+                              : launch_from_split(s.p, q, s.C, s.H, s.W, ctx->stream);
+    prof_end(ctx);
+    if (e != hipSuccess) { pool_release(ctx, q); return nullptr; }
+    s.alt = q;
+    return q;
 }
 
 static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* s2, const Slot* sres, Slot& dst,
@@ -727,35 +947,57 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             const int Ho = geo.H + 2 * L.pad - span, Wo = geo.W + 2 * L.pad - span;
             if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input %dx%dx%d too small", i, geo.D, geo.H, geo.W); break; }
             const int Co = L.head ? 1 : L.cout;
+            if (sres && (sres->H - 2 * L.res_crop != Ho || sres->W - 2 * L.res_crop != Wo || sres->C != L.cout)) {
+                rc = fail(ctx, "layer %d: residual geometry mismatch", i);
+                break;
+            }
+            // which kernels run the layer: the 2xf16 per-parity twin, a 2xf16 kernel, or the fp32 path
+            const bool exact2x = s2 && L.dims == 2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W;
+            const bool use_sphase = split && rt.sphase.valid && exact2x;
+            const bool use_split = split && rt.ks && !s2 && !use_sphase;
+            const bool stem_split = split && !use_sphase && !use_split && rt.ki_stem_split;
+            const bool split_dst = use_sphase || stem_split || (use_split && !L.head && rt.ks->epi != EPI_PLAIN_F32);
             // split tensors take the bytes of fp32 with the channels rounded up to whole 8-channel cells
-            const bool split_dst = split && !L.head;
             const size_t c_alloc = split_dst ? split_cells(Co) * 8 : (size_t)Co;
             float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
             if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
             set_dense(dst, p, Co, Do, Ho, Wo);
             dst.split = split_dst;
+            dst.alt = nullptr;
             dst.owned = (i != nl - 1);
-            if (sres && (sres->H - 2 * L.res_crop != Ho || sres->W - 2 * L.res_crop != Wo || sres->C != L.cout)) {
-                rc = fail(ctx, "layer %d: residual geometry mismatch", i);
-                break;
-            }
+            if (split_dst && i == nl - 1) { rc = fail(ctx, "layer %d: the result must leave as fp32", i); break; }
+            // sources in the format the chosen kernels read (converted once if the producer wrote the other one)
+            const bool want1 = use_sphase || use_split;
+            const bool want2 = use_sphase && !rt.sphase.ki_skip_stem;
+            Slot v1 = s1, v2, vres;
+            v1.p = slot_as(ctx, slots[L.src], want1);
+            v1.split = want1;
+            if (s2) { v2 = *s2; v2.p = slot_as(ctx, slots[L.src2], want2); v2.split = want2; }
+            if (sres) { vres = *sres; vres.p = slot_as(ctx, slots[L.res], use_split); vres.split = use_split; }
+            if (!v1.p || (s2 && !v2.p) || (sres && !vres.p)) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
-            if (split && rt.ks) {
-                if (!s1.split || (sres && !sres->split)) { rc = fail(ctx, "layer %d: 2xf16 kernel fed an fp32 tensor", i); break; }
-                rc = run_conv_split(ctx, rt, s1, sres, dst);
-            } else {
-                rc = run_conv(ctx, rt, s1, s2, sres, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0, split && rt.ki_stem_split);
-            }
+            if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
+            else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst);
+            else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
+                               (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
             const int Do = L.dims == 3 ? s1.D / 2 : 1, Ho = s1.H / 2, Wo = s1.W / 2;
             if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input too small to pool", i); break; }
-            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, (size_t)s1.C * Do * Ho * Wo * sizeof(float));
+            const bool sp = s1.split && i != nl - 1;          // pooled in the format the source has
+            const float* src_p = s1.p;
+            if (s1.split && !sp) { src_p = slot_as(ctx, slots[L.src], false); if (!src_p) { rc = fail(ctx, "conversion failed"); break; } }
+            const size_t c_alloc = sp ? split_cells(s1.C) * 8 : (size_t)s1.C;
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
             if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
-            set_dense(dst, p, s1.C, Do, Ho, Wo);
+            const int Cs = s1.C, Ds = s1.D, Hs = s1.H, Ws = s1.W;
+            set_dense(dst, p, Cs, Do, Ho, Wo);
+            dst.split = sp;
+            dst.alt = nullptr;
             dst.owned = (i != nl - 1);
             prof_begin(ctx, 2, 0);
-            hipError_t e = launch_maxpool2(s1.p, dst.p, s1.C, s1.D, s1.H, s1.W, L.dims, ctx->stream);
+            hipError_t e = sp ? launch_maxpool2_split(src_p, dst.p, Cs, Hs, Ws, ctx->stream)
+                              : launch_maxpool2(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream);
             prof_end(ctx);
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else {
@@ -763,13 +1005,15 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
         }
         // release intermediates whose last reader was this layer
         for (int s = 0; s < m->n_slots; ++s)
-            if (slots[s].set && slots[s].owned && m->last_use[s] == i) {
-                pool_release(ctx, slots[s].p);
-                slots[s].owned = false;
+            if (slots[s].set && m->last_use[s] == i) {
+                if (slots[s].owned) { pool_release(ctx, slots[s].p); slots[s].owned = false; }
+                if (slots[s].alt) { pool_release(ctx, slots[s].alt); slots[s].alt = nullptr; }
             }
     }
-    for (auto& s : slots)
+    for (auto& s : slots) {
         if (s.owned) { pool_release(ctx, s.p); s.owned = false; }
+        if (s.alt) { pool_release(ctx, s.alt); s.alt = nullptr; }
+    }
     return rc;
 }
 
@@ -1037,7 +1281,7 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
 // Denoise._denoise on a (strided) region: mean / unbiased std -> normalise -> network -> un-normalise.
 // mode 1: plain; mode 2: the un-normalisation also applies the volume's std*y+mu with g = {mu, std}.
 static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int mode = 1,
-                          const float* d_g = nullptr) {
+                          const float* d_g = nullptr, bool split = false) {
     tpz_ctx* ctx = m->ctx;
     float* nrm = next_nrm(ctx);
     prof_begin(ctx, 2, 0);
@@ -1055,24 +1299,19 @@ static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, in
     if (e != hipSuccess) { pool_release(ctx, xn); return fail(ctx, "affine_dev failed: %s", hipGetErrorString(e)); }
     std::vector<Slot> slots(m->n_slots);
     set_dense(slots[0], xn, 1, view.D, view.H, view.W);
-    const int rc = run_program(m, slots, d_out_dense, nrm);
+    const int rc = run_program(m, slots, d_out_dense, nrm, split);
     pool_release(ctx, xn);
     return rc;
 }
 
-int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out) {
-    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_2d: NULL argument");
+static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out, bool split) {
     tpz_ctx* ctx = m->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    int Do, Ho, Wo;
-    tpz_model_out_shape(m, 1, 8 * 64, 8 * 64, &Do, &Ho, &Wo);
-    if (Ho != 8 * 64 || Wo != 8 * 64) return fail(ctx, "tpz_denoise_2d: the model does not preserve the image size");
     const int s = patch + pad;
     const bool use_patch = patch > 0 && (s < H || s < W);     // denoise.py:329-330
     if (!use_patch) {
         Slot v;
         set_dense(v, const_cast<float*>(d_in), 1, 1, H, W);
-        return denoise_region(m, v, d_out);
+        return denoise_region(m, v, d_out, 1, nullptr, split);
     }
     for (int i = 0; i < H; i += patch)
         for (int j = 0; j < W; j += patch) {
@@ -1086,7 +1325,7 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
             v.cs = v.ps;
             float* tmp = (float*)pool_alloc(ctx, (size_t)ph * pw * sizeof(float));
             if (!tmp) return fail(ctx, "out of device memory");
-            int rc = denoise_region(m, v, tmp);
+            int rc = denoise_region(m, v, tmp, 1, nullptr, split);
             if (rc == 0) {
                 const int oi = i - si, oj = j - sj;
                 const int ch = std::min(patch, std::min(H - i, ph - oi)), cw = std::min(patch, std::min(W - j, pw - oj));
@@ -1100,6 +1339,25 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
             if (rc) return rc;
         }
     return 0;
+}
+
+int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out) {
+    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_2d: NULL argument");
+    tpz_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int Do, Ho, Wo;
+    tpz_model_out_shape(m, 1, 8 * 64, 8 * 64, &Do, &Ho, &Wo);
+    if (Ho != 8 * 64 || Wo != 8 * 64) return fail(ctx, "tpz_denoise_2d: the model does not preserve the image size");
+    if (m->split_ok && !ctx->exact) {
+        // 2xf16 path for the whole micrograph; any activation beyond the f16 range re-runs it on the fp32 kernels
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
+        if (denoise_2d_pass(m, d_in, H, W, patch, pad, d_out, true)) return 1;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_flag == 0) { ++m->n_split; return 0; }
+        ++m->n_fallback;
+    }
+    return denoise_2d_pass(m, d_in, H, W, patch, pad, d_out, false);
 }
 
 int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
