@@ -1,0 +1,85 @@
+// Timing ablations of conv_split_kernel (results are NOT numerically meaningful with ABL != 0).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I topaz_amd/csrc tools/split_ablate.hip -o tools/_bin/split_ablate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "conv_split.h"
+using namespace tpz;
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <class C, int EPI, int ABL>
+float run(const SplitArgs& a, dim3 grid, int iters) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, ABL>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(512), C::LDS_BYTES, 0, a);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(512), C::LDS_BYTES, 0, a);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(e));
+    return ms / iters;
+}
+
+template <class C, int EPI>
+int bench(const char* name, int cin, int cout, int H) {
+    const int span = C::D * (C::K - 1);
+    const int Ho = H - span;
+    const size_t cells_in = (cin + 7) / 8, cells_out = (cout + 7) / 8;
+    const size_t n_in = cells_in * 8 * H * H, n_out = cells_out * 8 * (size_t)Ho * Ho;
+    const int n_cog = (cout + C::MT - 1) / C::MT, n_chunks = (int)((cells_in + C::CC - 1) / C::CC);
+    const size_t n_w = (size_t)n_cog * n_chunks * C::NSTEP * C::W_STEP_BYTES / 4;
+    float *in, *w, *out, *res, *zeros, *vec;
+    unsigned* flag;
+    CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, cout * 4)); CHK(hipMalloc(&flag, 16));
+    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 16));
+    // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
+    std::vector<uint16_t> h(1 << 21);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x2800 + ((i * 2654435761u) >> 20) % 0x1000) | (uint16_t)(((i * 40503u) >> 7) & 1) << 15;
+    for (size_t o = 0; o < n_in * 4; o += h.size() * 2) CHK(hipMemcpy((char*)in + o, h.data(), std::min(h.size() * 2, n_in * 4 - o), hipMemcpyHostToDevice));
+    for (size_t o = 0; o < n_w * 4; o += h.size() * 2) CHK(hipMemcpy((char*)w + o, h.data(), std::min(h.size() * 2, n_w * 4 - o), hipMemcpyHostToDevice));
+    for (size_t o = 0; o < n_out * 4; o += h.size() * 2) CHK(hipMemcpy((char*)res + o, h.data(), std::min(h.size() * 2, n_out * 4 - o), hipMemcpyHostToDevice));
+    std::vector<float> ones(cout, 1e-3f);
+    CHK(hipMemcpy(vec, ones.data(), cout * 4, hipMemcpyHostToDevice));
+    SplitArgs a{};
+    a.in = (const uint4*)in; a.wpk = (const uint4*)w; a.wscale = vec; a.bias = vec; a.out = (uint4*)out; a.res = (const uint4*)res;
+    a.post_scale = vec; a.post_shift = vec; a.head_w = vec; a.head_out = out; a.zeros = zeros; a.flag = flag;
+    a.cells_in = a.cells_in1 = (int)cells_in; a.Hin = a.H1 = H; a.Win = a.W1 = H; a.Cout = cout; a.cells_out = (int)cells_out; a.Hout = Ho; a.Wout = Ho;
+    a.os = 1; a.Hfull = Ho; a.Wfull = Ho; a.Hres = Ho; a.Wres = Ho; a.n_chunks = n_chunks; a.xcd_swizzle = 1;
+    a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
+    a.tiles_x = (Ho + C::TW - 1) / C::TW;
+    a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
+    dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
+    const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
+    printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
+           n_chunks * C::NSTEP * a.cog_inner);
+#define RUN(ABL, label) { float ms = run<C, EPI, ABL>(a, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", label, ms, tf / (ms * 1e-3)); }
+    RUN(0, "baseline");
+    RUN(0, "baseline (again)");
+    RUN(1, "no epilogue loads/stores");
+    RUN(2, "no per-step DMA issue");
+    RUN(4, "no per-step barrier");
+    RUN(8, "A fragments read once per step");
+    RUN(1 | 2, "no epilogue, no DMA");
+    RUN(1 | 2 | 4, "no epilogue, no DMA, no barrier");
+    RUN(1 | 2 | 4 | 8, "no epilogue, no DMA, no barrier, few LDS reads");
+    RUN(16, "no MFMA (everything else)");
+    RUN(1 | 16, "no MFMA, no epilogue");
+    hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(zeros); hipFree(vec); hipFree(flag);
+    return 0;
+}
+
+int main() {
+    bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_RES>("K3 D4 MT128 RES (ResNet8 block2 conv1)", 64, 128, 2048);
+    bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_PLAIN>("K3 D4 MT128 PLAIN", 128, 128, 2048);
+    bench<SplitCfg<5, 4, 128, 16, 32, 2>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
+    bench<SplitCfg<3, 1, 64, 16, 32, 2>, EPI_RES>("K3 D1 MT64 RES (U-Net dec1.0 phase)", 96, 64, 1012);
+    return 0;
+}

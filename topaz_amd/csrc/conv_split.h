@@ -35,7 +35,9 @@
 namespace tpz {
 
 struct SplitArgs {
-    const uint4* in;          // split tensor: [2 planes][cells_in][Hin][Win] cells
+    const uint4* in;          // split tensor: [2 planes][cells_in1][H1][W1] cells
+    const uint4* in2;         // optional second source [2][cells_in - cells_in1][Hin][Win]: channels after those of
+                              // `in`, which is then nearest-upsampled to Hin x Win (fused upsample + concat)
     const uint4* wpk;         // packed weights (runtime.hip pack_weights_split)
     const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling
     const float* bias;        // [Cout] or nullptr
@@ -49,7 +51,8 @@ struct SplitArgs {
     const void* zeros;        // >= 16 bytes of zeros (source of padded / outside cells)
     unsigned* flag;           // set to 1 when a stored activation leaves the f16 range
     float head_b, slope;
-    int cells_in, Hin, Win;
+    int cells_in, Hin, Win;   // all input cells; logical input geometry
+    int cells_in1, H1, W1;    // cells and geometry of `in` (== cells_in, Hin, Win without a second source)
     int Cout, cells_out, Hout, Wout;
     int pad_x, pad_y;
     // output lattice as in conv_mfma.h: element (oy, ox) of the launch is element (oy*os + ooy, ox*os + oox)
@@ -121,7 +124,10 @@ struct SplitCfg {
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
 // EPI_PLAIN_F32 = plain epilogue storing fp32 planes, for a layer whose consumer is not on the 2xf16 path.
 enum { EPI_PLAIN_F32 = 5 };
-template <class C, int EPI>
+// ABL: timing-ablation switches for tools/split_ablate.hip only (production kernels use ABL = 0; results are not
+// meaningful otherwise):  1 no epilogue loads / stores   2 no per-step DMA issue   4 no per-step barrier
+//   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs
+template <class C, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -147,23 +153,33 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
     const int ybase = y0 - a.pad_y, xbase = x0 - a.pad_x;
 
     constexpr unsigned OOB = 0xffffffffu;
-    // ---- one-time tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell
+    // ---- tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell of a source
     if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
+    const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
+    auto compute_offsets = [&](bool second) {
+        const int Hs = second ? a.Hin : a.H1, Ws = second ? a.Win : a.W1;
 #pragma unroll 1
-    for (int i = 0; i < C::NR; ++i) {
-        const int g = i * C::THREADS + tid;
-        if (g < C::NPC) {
-            const int c = g / C::CELL_STRIDE;
-            const int rem = g - c * C::CELL_STRIDE;
-            const int r = rem / C::ITW, x = rem - r * C::ITW;
-            const int gy = ybase + r * D, gx = xbase + x;
-            unsigned off = OOB;
-            if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win)
-                off = (unsigned)((((size_t)c * a.Hin + gy) * a.Win + gx) * 16);
-            lds_tab[g] = off;
+        for (int i = 0; i < C::NR; ++i) {
+            const int g = i * C::THREADS + tid;
+            if (g < C::NPC) {
+                const int c = g / C::CELL_STRIDE;
+                const int rem = g - c * C::CELL_STRIDE;
+                const int r = rem / C::ITW, x = rem - r * C::ITW;
+                const int gy = ybase + r * D, gx = xbase + x;
+                unsigned off = OOB;
+                if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) {
+                    int sy = gy, sx = gx;
+                    if (!second && ups) { sy = nearest_src(gy, a.H1, a.Hin); sx = nearest_src(gx, a.W1, a.Win); }
+                    off = (unsigned)((((size_t)c * Hs + sy) * Ws + sx) * 16);
+                }
+                lds_tab[g] = off;              // read back by the same thread only
+            }
         }
-    }
-    const size_t plane_in = (size_t)a.cells_in * a.Hin * a.Win;       // cells per input plane
+    };
+    // chunks [0, chunks1) read `in`, the rest `in2` (the host guarantees cells_in1 % CC == 0 with a second source)
+    const int chunks1 = a.in2 ? a.cells_in1 / C::CC : a.n_chunks;
+    const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1;                       // cells per plane of `in`
+    const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * a.Hin * a.Win;      // ... of `in2`
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
 
@@ -171,9 +187,11 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
     auto issue_input = [&](int ch, int buf, int r) {
         const int g = r * C::THREADS + tid;
         if (g < C::NPC) {
-            const uint4* chunk = a.in + (size_t)ch * C::CC * a.Hin * a.Win;
+            const bool second = ch >= chunks1;
+            const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * a.Hin * a.Win
+                                        : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
             const void* bhi = uniform_ptr(chunk);
-            const void* blo = uniform_ptr(chunk + plane_in);
+            const void* blo = uniform_ptr(chunk + (second ? plane2 : plane1));
             unsigned off = lds_tab[g];
             if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
@@ -221,7 +239,8 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        __syncthreads();                       // tables written / previous co-group done with the buffers
+        __syncthreads();                       // slot table written / previous co-group done with the buffers
+        compute_offsets(chunks1 == 0);
 #pragma unroll 1
         for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r);
         issue_weights(wcog, 0, 0);
@@ -233,10 +252,13 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
             const int ch = s / C::NSTEP;
             const int j = s - ch * C::NSTEP;
             // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
-            if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1);
-            if (ch + 1 < a.n_chunks) {
+            if constexpr (!(ABL & 2)) {
+                if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1);
+                if (ch + 1 < a.n_chunks) {
+                    if (j == 0 && ch + 1 == chunks1) compute_offsets(true);      // switching to the second source
 #pragma unroll 1
-                for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r);
+                    for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r);
+                }
             }
             // ---- the step's MFMAs
             const unsigned char* bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[j * 4 + l4];
@@ -254,71 +276,106 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 if (m + 1 < MW) {
-                    ah[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
-                    ao[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (MW + m + 1) * 1024);
+                    if constexpr (!(ABL & 8)) {
+                        ah[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
+                        ao[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (MW + m + 1) * 1024);
+                    } else {
+                        ah[(m + 1) & 1] = ah[m & 1];
+                        ao[(m + 1) & 1] = ao[m & 1];
+                    }
                 }
+                if constexpr (!(ABL & 16)) {
 #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bh[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bo[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bo[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao[m & 1], bh[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NW; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao[m & 1], bh[n], acc[m][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) acc[m][n][0] += (float)ah[m & 1][0] * (float)bh[n][0] + (float)ao[m & 1][1] * (float)bo[n][1];
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next step has landed
-            __syncthreads();
+            if constexpr (!(ABL & 4)) __syncthreads();
         }
 
-        // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store
+        // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store.
+        // Channel-fragment (m) outer: the per-channel constants are fetched once per m, the residual cells of
+        // all NW pixel fragments are requested back to back before the first is used (the memory latency is
+        // paid once per m, not once per fragment), and invalid pixels are handled by clamped addresses +
+        // one predicate on the store.
         const size_t plane_out = (size_t)a.cells_out * a.Hfull * a.Wfull;
         const size_t plane_res = (size_t)a.cells_out * a.Hres * a.Wres;
         const bool has_bias = a.bias != nullptr;
+        int fyv[NW], fxv[NW];
+        bool okv[NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            const int trow = wave * C::RPW + n / NFC;
-            const int oy = y0 + trow * D;
+            const int oy = y0 + (wave * C::RPW + n / NFC) * D;
             const int ox = x0 + (n % NFC) * 16 + l15;
-            if (oy < a.Hout && ox < a.Wout) {
-                const int fy = oy * a.os + a.ooy, fx = ox * a.os + a.oox;     // position in the full output
+            okv[n] = oy < a.Hout && ox < a.Wout;
+            if constexpr ((ABL & 1) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
+            const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;   // clamped: loads stay in range
+            fyv[n] = cy * a.os + a.ooy;
+            fxv[n] = cx * a.os + a.oox;
+        }
 #pragma unroll
-                for (int m = 0; m < MW; ++m) {
-                    const int co0 = cog * C::MT + m * 16 + l4 * 4;        // 4 consecutive channels: half a cell
-                    const int cell = co0 >> 3, half = (co0 >> 2) & 1;
-                    float v[4];
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) {
-                        if (cell < a.cells_out) {
-                            const size_t rc = ((size_t)cell * a.Hres + (fy + a.res_crop)) * a.Wres + (fx + a.res_crop);
-                            const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
-                            join4(rp[0], rp[plane_res * 2], rv);
-                        }
-                    }
+        for (int m = 0; m < MW; ++m) {
+            const int co0 = cog * C::MT + m * 16 + l4 * 4;        // 4 consecutive channels: half a cell
+            const int cell = co0 >> 3, half = (co0 >> 2) & 1;
+            const int cellc = cell < a.cells_out ? cell : a.cells_out - 1;
+            float sc[4], bi[4], psc[4], psh[4], hw[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + r;
-                        const int cc = co < a.Cout ? co : a.Cout - 1;
-                        v[r] = acc[m][n][r] * a.wscale[cc] + (has_bias ? a.bias[cc] : 0.f);
-                        if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) v[r] += rv[r];
-                        if constexpr (EPI == EPI_RES_POST) v[r] = v[r] * a.post_scale[cc] + a.post_shift[cc];
-                        v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
-                        if (co >= a.Cout) v[r] = 0.f;
-                        if constexpr (EPI == EPI_HEAD) v[r] *= a.head_w[cc];
-                    }
-                    if constexpr (EPI == EPI_HEAD) {
-                        hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
-                    } else if constexpr (EPI == EPI_PLAIN_F32) {
+            for (int r = 0; r < 4; ++r) {
+                const int cc = co0 + r < a.Cout ? co0 + r : a.Cout - 1;
+                sc[r] = a.wscale[cc];
+                bi[r] = has_bias ? a.bias[cc] : 0.f;
+                if constexpr (EPI == EPI_RES_POST) { psc[r] = a.post_scale[cc]; psh[r] = a.post_shift[cc]; }
+                if constexpr (EPI == EPI_HEAD) hw[r] = a.head_w[cc];
+            }
+            uint2 rh[NW], rl[NW];
+            if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (co0 + r < a.Cout) a.out_f32[((size_t)(co0 + r) * a.Hfull + fy) * a.Wfull + fx] = v[r];
-                    } else {
+                for (int n = 0; n < NW; ++n) {
+                    const size_t rc = ((size_t)cellc * a.Hres + (fyv[n] + a.res_crop)) * a.Wres + (fxv[n] + a.res_crop);
+                    const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
+                    rh[n] = rp[0];
+                    rl[n] = rp[plane_res * 2];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                float v[4];
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) join4(rh[n], rl[n], rv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[m][n][r] * sc[r] + bi[r];
+                    if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) v[r] += rv[r];
+                    if constexpr (EPI == EPI_RES_POST) v[r] = v[r] * psc[r] + psh[r];
+                    v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+                    if (co0 + r >= a.Cout) v[r] = 0.f;
+                    if constexpr (EPI == EPI_HEAD) v[r] *= hw[r];
+                }
+                if constexpr (EPI == EPI_HEAD) {
+                    hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                } else if constexpr (EPI == EPI_PLAIN_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (okv[n] && co0 + r < a.Cout)
+                            a.out_f32[((size_t)(co0 + r) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]] = v[r];
+                } else {
+                    if (okv[n]) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
                         if (cell < a.cells_out) {
                             uint2 hi, lo;
                             split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + fy) * a.Wfull + fx) + half;
+                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + fyv[n]) * a.Wfull + fxv[n]) + half;
                             op[0] = hi;
                             op[plane_out * 2] = lo;
                         }

@@ -202,6 +202,7 @@ struct LayerRT {
     tpz_layer L;
     const ConvKernelInfo* ki = nullptr;   // nullptr -> direct kernel
     int n_cog = 1, n_chunks = 1, cog_inner = 1;
+    int c1 = 0, c2 = 0;                   // channels of the first / second source
     float* d_wpk = nullptr;               // packed (MFMA) or raw (direct) weights
     float* d_bias = nullptr;
     float* d_post_scale = nullptr;
@@ -409,6 +410,7 @@ static int prepare_phases(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const 
 static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const float* blob, size_t n_floats,
                          LayerRT& rt, int c1 = 0, int c2 = 0) {
     rt.L = L;
+    rt.c1 = c1; rt.c2 = c2;
     if (L.op != TPZ_OP_CONV) return 0;
     if (L.dims != 2 && L.dims != 3) return fail(ctx, "conv: dims must be 2 or 3");
     const size_t taps = (L.dims == 3 ? (size_t)L.k * L.k * L.k : (size_t)L.k * L.k);
@@ -589,7 +591,12 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         if (L.op != TPZ_OP_CONV || !rt.ki || rt.ki->cin1) continue;
         if (L.src2 >= 0) {
             if (prepare_split_phases(ctx, m, blob + L.w_off, rt)) return 1;
-            reads[i] = rt.sphase.valid ? 1 : 0;
+            // any other geometry: the same kernel family with the upsample + concat folded into its loader
+            if (rt.ki->epi == EPI_PLAIN && rt.c1 + rt.c2 == L.cin) {
+                rt.ks = pick_split(L.k, L.dil, L.cout, EPI_PLAIN);
+                if (rt.ks && rt.c1 % (8 * rt.ks->CC) != 0) rt.ks = nullptr;
+            }
+            reads[i] = (rt.sphase.valid || rt.ks) ? 1 : 0;
             continue;
         }
         rt.ks = pick_split(L.k, L.dil, L.cout, rt.ki->epi);
@@ -621,7 +628,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
             continue;
         }
         if (rt.ks) {
-            if (!L.head && !wanted && rt.ks->epi == EPI_PLAIN) {
+            if (!L.head && !wanted && rt.ks->epi == EPI_PLAIN && L.src2 < 0) {
                 const SplitKernelInfo* f = find_split(L.k, L.dil, rt.ks->MT, EPI_PLAIN_F32);
                 if (!f) f = pick_split(L.k, L.dil, L.cout, EPI_PLAIN_F32);
                 if (f) rt.ks = f;
@@ -708,7 +715,8 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
 }
 
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
-static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst) {
+static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst,
+                          const Slot* s2 = nullptr) {
     const tpz_layer& L = rt.L;
     const SplitKernelInfo& ks = *rt.ks;
     SplitArgs a;
@@ -728,8 +736,16 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.zeros = ctx->d_zeros;
     a.flag = ctx->d_flag;
     a.slope = L.slope;
-    a.cells_in = (int)split_cells(s1.C);
-    a.Hin = s1.H; a.Win = s1.W;
+    a.cells_in1 = (int)split_cells(s1.C);
+    a.H1 = s1.H; a.W1 = s1.W;
+    if (s2) {
+        a.in2 = reinterpret_cast<const uint4*>(s2->p);
+        a.cells_in = a.cells_in1 + (int)split_cells(s2->C);
+        a.Hin = s2->H; a.Win = s2->W;
+    } else {
+        a.cells_in = a.cells_in1;
+        a.Hin = s1.H; a.Win = s1.W;
+    }
     a.Cout = L.cout;
     a.cells_out = (int)split_cells(L.cout);
     a.Hout = dst.H; a.Wout = dst.W;
@@ -805,8 +821,8 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.zeros = ctx->d_zeros;
         a.flag = ctx->d_flag;
         a.slope = 1.f;
-        a.cells_in = (int)split_cells(s2.C);
-        a.Hin = s2.H; a.Win = s2.W;
+        a.cells_in = a.cells_in1 = (int)split_cells(s2.C);
+        a.Hin = a.H1 = s2.H; a.Win = a.W1 = s2.W;
         a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
         a.Hout = dst.H; a.Wout = dst.W;
         a.pad_x = a.pad_y = L.pad;
@@ -829,8 +845,8 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.zeros = ctx->d_zeros;
         a.flag = ctx->d_flag;
         a.slope = L.slope;
-        a.cells_in = (int)split_cells(s1.C);
-        a.Hin = s1.H; a.Win = s1.W;
+        a.cells_in = a.cells_in1 = (int)split_cells(s1.C);
+        a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
         a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
         a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of this parity
         a.pad_x = phase_pad(L.k, px); a.pad_y = phase_pad(L.k, py);
@@ -954,7 +970,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             // which kernels run the layer: the 2xf16 per-parity twin, a 2xf16 kernel, or the fp32 path
             const bool exact2x = s2 && L.dims == 2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W;
             const bool use_sphase = split && rt.sphase.valid && exact2x;
-            const bool use_split = split && rt.ks && !s2 && !use_sphase;
+            const bool use_split = split && rt.ks && !use_sphase;
             const bool stem_split = split && !use_sphase && !use_split && rt.ki_stem_split;
             const bool split_dst = use_sphase || stem_split || (use_split && !L.head && rt.ks->epi != EPI_PLAIN_F32);
             // split tensors take the bytes of fp32 with the channels rounded up to whole 8-channel cells
@@ -968,7 +984,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (split_dst && i == nl - 1) { rc = fail(ctx, "layer %d: the result must leave as fp32", i); break; }
             // sources in the format the chosen kernels read (converted once if the producer wrote the other one)
             const bool want1 = use_sphase || use_split;
-            const bool want2 = use_sphase && !rt.sphase.ki_skip_stem;
+            const bool want2 = use_sphase ? !rt.sphase.ki_skip_stem : use_split;
             Slot v1 = s1, v2, vres;
             v1.p = slot_as(ctx, slots[L.src], want1);
             v1.split = want1;
@@ -977,7 +993,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (!v1.p || (s2 && !v2.p) || (sres && !vres.p)) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
             if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
-            else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst);
+            else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr);
             else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
                                (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
         } else if (L.op == TPZ_OP_MAXPOOL2) {
