@@ -239,8 +239,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (U-Net: fp32 MFMA; scoring convs: fp32 operands carried as two f16 halves on the f16 MFMA, '
-                     'f32 accumulate, fp32-level error, fp32 re-run on f16-range overflow)',
+            'dtype': 'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
+                     'multiply-add accumulated in f32 -- fp32-level error, fp32-MFMA re-run on f16-range overflow; '
+                     '1-channel stems, the 1-output-channel last conv and NMS in fp32)',
             'data': 'synthetic (N(0,1) micrographs seed 1000+i; seeded random weights of the named architectures)',
             'config': {
                 'workload': {'pipeline': 'denoise(unet b11/t5 nf48, -s 1024 -p 500) -> score(resnet8 u64, filled) -> NMS(r=14,t=-6)',

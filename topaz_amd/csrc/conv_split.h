@@ -313,15 +313,17 @@ __global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
         const bool has_bias = a.bias != nullptr;
         int fyv[NW], fxv[NW];
         bool okv[NW];
+        if constexpr (EPI != EPI_HEAD) {       // (the fused head stores nothing here: every pixel just accumulates)
 #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int oy = y0 + (wave * C::RPW + n / NFC) * D;
-            const int ox = x0 + (n % NFC) * 16 + l15;
-            okv[n] = oy < a.Hout && ox < a.Wout;
-            if constexpr ((ABL & 1) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
-            const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;   // clamped: loads stay in range
-            fyv[n] = cy * a.os + a.ooy;
-            fxv[n] = cx * a.os + a.oox;
+            for (int n = 0; n < NW; ++n) {
+                const int oy = y0 + (wave * C::RPW + n / NFC) * D;
+                const int ox = x0 + (n % NFC) * 16 + l15;
+                okv[n] = oy < a.Hout && ox < a.Wout;
+                if constexpr ((ABL & 1) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
+                const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;   // clamped: loads stay in range
+                fyv[n] = cy * a.os + a.ooy;
+                fxv[n] = cx * a.os + a.oox;
+            }
         }
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
