@@ -239,7 +239,8 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
+            'dtype': 'f32 (fp32 MFMA kernels only: TPZ_EXACT_FP32 is set)' if os.environ.get('TPZ_EXACT_FP32') else
+                     'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
                      'multiply-add accumulated in f32 -- fp32-level error, fp32-MFMA re-run on f16-range overflow; '
                      '1-channel stems, the 1-output-channel last conv and NMS in fp32)',
             'data': 'synthetic (N(0,1) micrographs seed 1000+i; seeded random weights of the named architectures)',
