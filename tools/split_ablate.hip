@@ -14,10 +14,10 @@ float run(const SplitArgs& a, dim3 grid, int iters) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(512), C::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(512), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;

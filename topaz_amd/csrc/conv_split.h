@@ -69,17 +69,21 @@ struct SplitSlot {
     int ky, kx, c;            // ky < 0: padding slot (zero weights)
 };
 
-template <int K_, int D_, int MT_, int TH_, int TW_, int CC_>
+template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8>
 struct SplitCfg {
     static constexpr int K = K_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
-    static constexpr int WAVES = 8, THREADS = 512;
+    // 8 waves: one workgroup per CU (the big dilated tiles need most of the LDS); 4 waves: two per CU, so that
+    // one workgroup's prologue / epilogue / barrier waits overlap the other's MFMAs (small-halo, short-K layers)
+    static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_, WGS_PER_CU = WAVES_ == 8 ? 1 : 2;
     static constexpr int MW = MT / 16;
     static constexpr int RPW = TH / WAVES;
     static constexpr int NFC = TW / 16;
     static constexpr int NW = RPW * NFC;
     static constexpr int ITH = TH + K - 1;
-    static constexpr int ITW = (TW + (K - 1) * D + 15) / 16 * 16;   // rows start on the same LDS bank slot
-    static constexpr int CELL_STRIDE = ITH * ITW;                   // cells per 8-channel cell plane (x16)
+    // the two 16-byte reads of a ds_read_b128 lane group must be a multiple of 256 B apart: vertically adjacent
+    // taps (CC = 1) need rows of a multiple of 16 cells, the two cells of one tap (CC even) only a cell plane of one
+    static constexpr int ITW = (CC == 1) ? (TW + (K - 1) * D + 15) / 16 * 16 : TW + (K - 1) * D;
+    static constexpr int CELL_STRIDE = (ITH * ITW + 15) / 16 * 16;  // cells per 8-channel cell plane
     static constexpr int NPC = CC * CELL_STRIDE;                    // cells per (hi | lo) plane of a chunk
     static constexpr int PLANE_BYTES = NPC * 16;
     static constexpr int IN_BUF = 2 * PLANE_BYTES;
@@ -118,7 +122,8 @@ struct SplitCfg {
     static constexpr int LDS_BYTES = OFF_SLOT + NSTEP * 16;
     static_assert(TH % WAVES == 0 && TW % 16 == 0 && MT % 16 == 0, "tile shape");
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS per workgroup");
+    static_assert(LDS_BYTES <= 160 * 1024 / WGS_PER_CU, "LDS per workgroup");
+    static_assert(WAVES == 8 || WAVES == 4, "waves per workgroup");
 };
 
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
@@ -128,7 +133,7 @@ enum { EPI_PLAIN_F32 = 5 };
 // meaningful otherwise):  1 no epilogue loads / stores   2 no per-step DMA issue   4 no per-step barrier
 //   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs
 template <class C, int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void conv_split_kernel(const SplitArgs a) {
+__global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned* lds_tab = reinterpret_cast<unsigned*>(lds + C::OFF_TAB);

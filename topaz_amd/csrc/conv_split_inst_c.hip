@@ -1,5 +1,7 @@
 #include "conv_split_registry.h"
-//               K  D  MT  TH  TW  CC
-TPZ_SPLIT_RESID(3, 1, 64, 16, 32, 2)
-TPZ_SPLIT_RESID(3, 2, 64, 16, 32, 2)
-TPZ_SPLIT_RESID(3, 4, 64, 16, 32, 2)
+// 64-channel ResidA layers.  d = 1 (also the U-Net dec1.0 parity kernels): 4-wave workgroups, two per CU;
+// d = 2, 4: 8-wave (measured equal or faster there)
+//                K  D  MT  TH  TW  CC
+TPZ_SPLIT4_RESID(3, 1, 64, 8,  32, 2)
+TPZ_SPLIT_RESID( 3, 2, 64, 16, 32, 2)
+TPZ_SPLIT_RESID( 3, 4, 64, 16, 32, 2)

@@ -4,8 +4,7 @@
 // and dec1.2, whose consumer (the 1-channel last conv) reads fp32.
 #include "conv_split_registry.h"
 //         K  D  MT  TH  TW  CC  EPI
-TPZ_SPLIT(3, 1, 48, 16, 32, 2, ::tpz::EPI_PLAIN)
-TPZ_SPLIT(3, 1, 96, 16, 32, 2, ::tpz::EPI_PLAIN)
-TPZ_SPLIT(2, 1, 96, 16, 32, 2, ::tpz::EPI_RES)
-TPZ_SPLIT(3, 1, 64, 16, 32, 2, ::tpz::EPI_RES)
-TPZ_SPLIT(5, 1, 32, 16, 32, 2, ::tpz::EPI_PLAIN_F32)
+TPZ_SPLIT4(3, 1, 48, 8, 32, 2, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4(3, 1, 96, 8, 32, 2, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4(2, 1, 96, 8, 32, 2, ::tpz::EPI_RES)
+TPZ_SPLIT4(5, 1, 32, 8, 32, 2, ::tpz::EPI_PLAIN_F32)

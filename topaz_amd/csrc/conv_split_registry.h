@@ -8,7 +8,7 @@ namespace tpz {
 
 struct SplitKernelInfo {
     int K, D, MT, epi;
-    int TH, TW, CC, NSTEP, W_STEP_BYTES, lds_bytes;
+    int TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes;
     SplitSlot (*slot)(int step, int kb);
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
     char name[160];
@@ -38,18 +38,25 @@ struct SplitRegistrar {
     SplitRegistrar() {
         SplitKernelInfo i;
         i.K = C::K; i.D = C::D; i.MT = C::MT; i.epi = EPI;
-        i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
+        i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.WAVES = C::WAVES; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
         i.lds_bytes = C::LDS_BYTES;
         i.slot = &split_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
-        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,EPI=%d>", i.K, i.D, i.MT,
-                 i.TH, i.TW, i.CC, i.epi);
+        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.D, i.MT,
+                 i.TH, i.TW, i.CC, i.WAVES, i.epi);
         register_split(i);
     }
 };
 
 #define TPZ_SPLIT(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+// 4-wave workgroups, two per CU
+#define TPZ_SPLIT4(K, D, MT, TH, TW, CC, EPI) \
+    static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+#define TPZ_SPLIT4_RESID(K, D, MT, TH, TW, CC)        \
+    TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \
+    TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_RES)   \
+    TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_RES_POST)
 // ResidA layers: plain (conv0), residual and residual + eval-BN (conv1)
 #define TPZ_SPLIT_RESID(K, D, MT, TH, TW, CC)        \
     TPZ_SPLIT(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \
