@@ -194,3 +194,28 @@ def test_unet_patched_denoise_split_matches_oracle(gpu_ctx):
     y = dn.denoise_device(torch.from_numpy(x).cuda(), 128, 64).cpu().numpy()
     assert _err(y, ref) <= 1e-4
     assert dn.model.device_model.split_stats()[1] >= 1
+
+
+def test_unet3d_on_split_path_matches_oracle(gpu_ctx):
+    """UDenoiseNet3D (48 filters) on the plane-stacked 2xf16 kernels: 3-D convs as 2-D tiles over stacked planes,
+    8-parity decoder kernels, 3-D split max-pool, fp32 only in the two stems and the 1-channel last conv."""
+    from oracle import denoising as oden
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)
+    d3 = Denoise3D(DenoiseNet('unet-3d', sd))
+    x = (np.random.RandomState(10).randn(64, 64, 96) * 2 + 0.5).astype(np.float32)
+    ref = oden.denoise_whole('unet-3d', oden.to_torch_sd(sd), torch.from_numpy(x))
+    dm = d3.model.device_model
+    before = dm.split_stats()
+    assert before[0], 'the 3-D U-Net should be eligible for the 2xf16 path'
+    y = dm.denoise_3d(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
+    after = dm.split_stats()
+    assert after[1] == before[1] + 1 and after[2] == before[2]
+    assert _err(y, ref) <= 1e-4
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = dm.denoise_3d(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
+    finally:
+        gpu_ctx.set_exact(False)
+    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4

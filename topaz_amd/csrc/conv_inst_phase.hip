@@ -15,5 +15,6 @@ TPZ_CONV3D(2, 1, 16, 4, 4, 32, 1, 4, false)
 TPZ_CONV3D(2, 1, 64, 2, 4, 32, 1, 4, false)
 TPZ_CONV3D(2, 1, 96, 2, 4, 32, 1, 4, false)
 TPZ_CONV3D_EPI(3, 1, 64, 2, 4, 32, 1, 9, true, ::tpz::EPI_RES)
+TPZ_CONV3D_EPI(3, 1, 64, 2, 4, 32, 1, 9, true, ::tpz::EPI_SPLIT)    // ... and its dec1.0 skip part
 TPZ_CONV3D_EPI(3, 1, 16, 4, 4, 32, 1, 3, false, ::tpz::EPI_RES)
 TPZ_CONV3D_EPI(3, 1, 96, 2, 4, 32, 1, 3, false, ::tpz::EPI_RES)

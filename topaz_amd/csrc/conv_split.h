@@ -25,6 +25,10 @@
 // Pipeline: one stage = one step.  Weights of step s+1 and, spread over the steps of a chunk, the input
 //   tile of the next chunk arrive by LDS-DMA (global_load_lds_dwordx4: one cell per lane) into the other
 //   LDS buffers while step s computes; one barrier per step.
+// 3-D convolutions (UDenoiseNet3D, denoising/models.py:452-564) run on the same 2-D tiles: output plane z of a
+//   k^3 conv is the 2-D k^2 conv of the k input planes z+kz-pad stacked as channels, so the K loop walks
+//   "virtual cells" v = kz * cells + c (SplitArgs::KZ); one grid-z slice per output plane.  Every input plane is
+//   read by k output planes (a 3-D LDS tile's halo re-reads as much), the K loop is k times longer (good).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,7 +63,10 @@ struct SplitArgs {
     // of the [Hfull][Wfull] output; the residual is read at the same full-tensor position (+ res_crop)
     int os, ooy, oox, Hfull, Wfull;
     int Hres, Wres, res_crop;
-    int n_chunks;             // chunks of CC cells
+    // 3-D mode (KZ >= 1 with tensors [cells][D][H][W]; 2-D: KZ = 1, every D = 1, ncz = grid z).  Single source only.
+    int KZ, pad_z, Din, Dout, ooz, Dfull, Dres;
+    int ncz;                  // co-group slices of grid z: blockIdx.z = plane * ncz + co-group slice
+    int n_chunks;             // chunks of CC (virtual) cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
     int xcd_swizzle;
@@ -156,6 +163,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const int y0 = (by / D) * (C::TH * D) + (by % D);
     const int x0 = bx * C::TW;
     const int ybase = y0 - a.pad_y, xbase = x0 - a.pad_x;
+    const int oz = (int)blockIdx.z / a.ncz;                  // output plane of the launch lattice (0 in 2-D)
+    const int cogz = (int)blockIdx.z - oz * a.ncz;
+    const bool vol = a.KZ > 1 || a.Din > 1;                  // plane-stacked 3-D addressing
 
     constexpr unsigned OOB = 0xffffffffu;
     // ---- tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell of a source
@@ -175,7 +185,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) {
                     int sy = gy, sx = gx;
                     if (!second && ups) { sy = nearest_src(gy, a.H1, a.Hin); sx = nearest_src(gx, a.W1, a.Win); }
-                    off = (unsigned)((((size_t)c * Hs + sy) * Ws + sx) * 16);
+                    // 3-D: the in-plane part only; the (cell, plane) part is added per chunk in issue_input
+                    off = vol ? (unsigned)(((size_t)sy * Ws + sx) * 16) : (unsigned)((((size_t)c * Hs + sy) * Ws + sx) * 16);
                 }
                 lds_tab[g] = off;              // read back by the same thread only
             }
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     };
     // chunks [0, chunks1) read `in`, the rest `in2` (the host guarantees cells_in1 % CC == 0 with a second source)
     const int chunks1 = a.in2 ? a.cells_in1 / C::CC : a.n_chunks;
-    const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1;                       // cells per plane of `in`
+    const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1 * (vol ? a.Din : 1);   // cells per plane of `in`
     const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * a.Hin * a.Win;      // ... of `in2`
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
@@ -195,10 +206,20 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const bool second = ch >= chunks1;
             const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * a.Hin * a.Win
                                         : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
-            const void* bhi = uniform_ptr(chunk);
-            const void* blo = uniform_ptr(chunk + (second ? plane2 : plane1));
+            const void* bhi = uniform_ptr(vol ? a.in : chunk);
+            const void* blo = uniform_ptr((vol ? a.in : chunk) + (second ? plane2 : plane1));
             unsigned off = lds_tab[g];
-            if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
+            if (!vol) {
+                if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
+            } else {
+                // virtual cell v = kz * cells + c: cell c of input plane oz + kz - pad_z (32-bit byte offsets from
+                // the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
+                const int v = ch * C::CC + g / C::CELL_STRIDE;
+                const int kz = v / a.cells_in, c = v - kz * a.cells_in;
+                const int iz = oz + kz - a.pad_z;
+                if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
+                else if (off != OOB) off += (unsigned)((((size_t)c * a.Din + iz) * a.Hin) * a.Win * 16);
+            }
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
             if (!__any(off == OOB)) {
                 glds_b128(off, bhi, dst);
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
-        const int cog = blockIdx.z * a.cog_inner + cg;
+        const int cog = cogz * a.cog_inner + cg;
         const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)cog * w_cog_bytes;
         f32x4 acc[MW][NW];
 #pragma unroll
@@ -313,8 +334,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         // all NW pixel fragments are requested back to back before the first is used (the memory latency is
         // paid once per m, not once per fragment), and invalid pixels are handled by clamped addresses +
         // one predicate on the store.
-        const size_t plane_out = (size_t)a.cells_out * a.Hfull * a.Wfull;
-        const size_t plane_res = (size_t)a.cells_out * a.Hres * a.Wres;
+        const int fz = oz * a.os + a.ooz;                      // output plane in the full tensor (0 in 2-D)
+        const size_t plane_out = (size_t)a.cells_out * a.Dfull * a.Hfull * a.Wfull;
+        const size_t plane_res = (size_t)a.cells_out * a.Dres * a.Hres * a.Wres;
         const bool has_bias = a.bias != nullptr;
         int fyv[NW], fxv[NW];
         bool okv[NW];
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) {
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
-                    const size_t rc = ((size_t)cellc * a.Hres + (fyv[n] + a.res_crop)) * a.Wres + (fxv[n] + a.res_crop);
+                    const size_t rc = (((size_t)cellc * a.Dres + fz) * a.Hres + (fyv[n] + a.res_crop)) * a.Wres + (fxv[n] + a.res_crop);
                     const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
                     rh[n] = rp[0];
                     rl[n] = rp[plane_res * 2];
@@ -374,7 +396,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (okv[n] && co0 + r < a.Cout)
-                            a.out_f32[((size_t)(co0 + r) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]] = v[r];
+                            a.out_f32[(((size_t)(co0 + r) * a.Dfull + fz) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]] = v[r];
                 } else {
                     if (okv[n]) {
 #pragma unroll
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         if (cell < a.cells_out) {
                             uint2 hi, lo;
                             split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + fyv[n]) * a.Wfull + fxv[n]) + half;
+                            uint2* op = reinterpret_cast<uint2*>(a.out + (((size_t)cell * a.Dfull + fz) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]) + half;
                             op[0] = hi;
                             op[plane_out * 2] = lo;
                         }

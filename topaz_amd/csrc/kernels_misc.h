@@ -14,7 +14,7 @@ hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float 
 hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, int pitch, const float* d_p, float* y,
                              hipStream_t s);
 hipError_t launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t s);
-hipError_t launch_maxpool2_split(const void* in, void* out, int C, int H, int W, hipStream_t s);
+hipError_t launch_maxpool2_split(const void* in, void* out, int C, int D, int H, int W, int dims, hipStream_t s);
 hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsigned* flag, hipStream_t s);
 hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* dst, long long dps, int dpitch, int bd,

@@ -164,23 +164,26 @@ hipError_t launch_maxpool2(const float* in, float* out, int C, int D, int H, int
     return hipGetLastError();
 }
 
-// MaxPool2d(2) on split cells: the (hi, lo) pair of the largest of the four values is selected per channel,
-// so the result equals the pooled fp32 value exactly.
+// MaxPool2d(2) / MaxPool3d(2) on split cells: the (hi, lo) pair of the largest of the 4 / 8 values is selected
+// per channel, so the result equals the pooled fp32 value exactly.
 __global__ __launch_bounds__(256) void maxpool2_split_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
-                                                             int cells, int H, int W, int Ho, int Wo) {
-    const size_t n = (size_t)cells * Ho * Wo;
-    const size_t plane_in = (size_t)cells * H * W;
+                                                             int cells, int D, int H, int W, int Do, int Ho, int Wo,
+                                                             int dims) {
+    const size_t n = (size_t)cells * Do * Ho * Wo;
+    const size_t plane_in = (size_t)cells * D * H * W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int x = (int)(i % Wo);
-        const size_t t = i / Wo;
+        size_t t = i / Wo;
         const int y = (int)(t % Ho);
-        const size_t c = t / Ho;
-        const size_t p = (c * H + 2 * y) * W + 2 * x;
-        const size_t idx[4] = {p, p + 1, p + W, p + W + 1};
-        f16x8 bh = __builtin_bit_cast(f16x8, in[idx[0]]), bl = __builtin_bit_cast(f16x8, in[plane_in + idx[0]]);
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const f16x8 h = __builtin_bit_cast(f16x8, in[idx[k]]), l = __builtin_bit_cast(f16x8, in[plane_in + idx[k]]);
+        t /= Ho;
+        const int z = (int)(t % Do);
+        const size_t c = t / Do;
+        const size_t p = ((c * D + (dims == 3 ? 2 * z : 0)) * H + 2 * y) * W + 2 * x;
+        f16x8 bh = __builtin_bit_cast(f16x8, in[p]), bl = __builtin_bit_cast(f16x8, in[plane_in + p]);
+        const int nz = dims == 3 ? 2 : 1;
+        for (int k = 1; k < 4 * nz; ++k) {
+            const size_t q = p + (size_t)(k >> 2) * H * W + (size_t)((k >> 1) & 1) * W + (k & 1);
+            const f16x8 h = __builtin_bit_cast(f16x8, in[q]), l = __builtin_bit_cast(f16x8, in[plane_in + q]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 // hi + lo compares as the fp32 value it stands for
@@ -193,13 +196,13 @@ __global__ __launch_bounds__(256) void maxpool2_split_kernel(const uint4* __rest
     }
 }
 
-hipError_t launch_maxpool2_split(const void* in, void* out, int C, int H, int W, hipStream_t s) {
-    const int Ho = H / 2, Wo = W / 2;
-    const size_t n = split_cells(C) * (size_t)Ho * Wo;
+hipError_t launch_maxpool2_split(const void* in, void* out, int C, int D, int H, int W, int dims, hipStream_t s) {
+    const int Do = dims == 3 ? D / 2 : 1, Ho = H / 2, Wo = W / 2;
+    const size_t n = split_cells(C) * (size_t)Do * Ho * Wo;
     if (n == 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(maxpool2_split_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, (uint4*)out,
-                       (int)split_cells(C), H, W, Ho, Wo);
+                       (int)split_cells(C), dims == 3 ? D : 1, H, W, Do, Ho, Wo, dims);
     return hipGetLastError();
 }
 

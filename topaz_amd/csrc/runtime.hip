@@ -224,8 +224,8 @@ struct LayerRT {
         const SplitKernelInfo* ks_skip = nullptr;      // k-tap kernel over a multi-channel skip source, EPI_PLAIN
         const ConvKernelInfo* ki_skip_stem = nullptr;  // 1-channel skip source: fp32 CIN1 kernel, EPI_SPLIT
         int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
-        void* d_w_low[4] = {nullptr, nullptr, nullptr, nullptr};
-        float* d_ws_low[4] = {nullptr, nullptr, nullptr, nullptr};
+        void* d_w_low[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        float* d_ws_low[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         void* d_w_skip = nullptr;
         float* d_ws_skip = nullptr;
     } sphase;
@@ -511,8 +511,23 @@ static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi) {
     return best;
 }
 
+// kz_n > 1: 3-D weights [cout][cin][kz][k][k] are laid out for the plane-stacked 2-D kernel (conv_split.h): the
+// input channels of plane kz become channels [kz*cells*8, ...) of a 2-D conv with kz_n * cells * 8 input channels
 static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInfo& ks, const float* w, int cout, int cin,
-                                int* n_cog, int* n_chunks, void** d_w, float** d_ws) {
+                                int* n_cog, int* n_chunks, void** d_w, float** d_ws, int kz_n = 1) {
+    std::vector<float> stacked;
+    if (kz_n > 1) {
+        const int c8 = (int)split_cells(cin) * 8, k = ks.K;
+        const size_t taps2 = (size_t)k * k;
+        stacked.assign((size_t)cout * kz_n * c8 * taps2, 0.f);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int kz = 0; kz < kz_n; ++kz)
+                    memcpy(&stacked[((size_t)co * kz_n * c8 + (size_t)kz * c8 + ci) * taps2],
+                           &w[(((size_t)co * cin + ci) * kz_n + kz) * taps2], taps2 * sizeof(float));
+        w = stacked.data();
+        cin = kz_n * c8;
+    }
     *n_cog = (cout + ks.MT - 1) / ks.MT;
     *n_chunks = (int)((split_cells(cin) + ks.CC - 1) / ks.CC);
     std::vector<uint16_t> packed;
@@ -529,35 +544,39 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
     const tpz_layer& L = rt.L;
     const LayerRT::Phase& ph = rt.phase;
     LayerRT::SplitPhase& sp = rt.sphase;
-    if (!ph.valid || L.dims != 2 || ph.c1 % 8 != 0) return 0;
-    const int k = L.k, k1 = ph.k1, c1 = ph.c1, c2 = ph.c2;
+    if (!ph.valid || ph.c1 % 8 != 0) return 0;
+    const int k = L.k, k1 = ph.k1, c1 = ph.c1, c2 = ph.c2, dims = L.dims;
+    const int kz_n = dims == 3 ? k : 1, k1z_n = dims == 3 ? k1 : 1;
     sp.ks_low = pick_split(k1, 1, L.cout, EPI_RES);
     if (!sp.ks_low) return 0;
     if (c2 == 1) {
         // same tile and weight packing as the fp32 skip kernel of prepare_phases: its packed weights are reused
         if (!ph.ki_skip->cin1) return 0;
-        sp.ki_skip_stem = find_conv(2, k, 1, ph.ki_skip->MT, true, EPI_SPLIT);
+        sp.ki_skip_stem = find_conv(dims, k, 1, ph.ki_skip->MT, true, EPI_SPLIT);
         if (!sp.ki_skip_stem || ph.n_cog_skip != 1) return 0;
     } else {
         sp.ks_skip = pick_split(k, 1, L.cout, EPI_PLAIN);
         if (!sp.ks_skip) return 0;
     }
-    const size_t taps = (size_t)k * k, taps1 = (size_t)k1 * k1;
+    const size_t taps = (size_t)kz_n * k * k, taps1 = (size_t)k1z_n * k1 * k1;
     std::vector<double> acc;
     std::vector<float> eff;
-    for (int p = 0; p < 4; ++p) {
-        const int px = p & 1, py = (p >> 1) & 1;
+    for (int p = 0; p < (1 << dims); ++p) {
+        const int px = p & 1, py = (p >> 1) & 1, pz = dims == 3 ? (p >> 2) & 1 : 0;
         acc.assign((size_t)L.cout * c1 * taps1, 0.0);
         for (int co = 0; co < L.cout; ++co)
             for (int ci = 0; ci < c1; ++ci)
-                for (int ky = 0; ky < k; ++ky)
-                    for (int kx = 0; kx < k; ++kx)
-                        acc[((size_t)co * c1 + ci) * taps1 + (size_t)phase_tap(k, py, ky) * k1 + phase_tap(k, px, kx)] +=
-                            (double)w[((size_t)co * L.cin + ci) * taps + (size_t)ky * k + kx];
+                for (int kz = 0; kz < kz_n; ++kz)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx) {
+                            const int tz = dims == 3 ? phase_tap(k, pz, kz) : 0;
+                            acc[((size_t)co * c1 + ci) * taps1 + ((size_t)tz * k1 + phase_tap(k, py, ky)) * k1 + phase_tap(k, px, kx)] +=
+                                (double)w[((size_t)co * L.cin + ci) * taps + ((size_t)kz * k + ky) * k + kx];
+                        }
         eff.resize(acc.size());
         for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
         if (upload_split_weights(ctx, m, *sp.ks_low, eff.data(), L.cout, c1, &sp.n_cog_low, &sp.n_chunks_low,
-                                 &sp.d_w_low[p], &sp.d_ws_low[p])) return 1;
+                                 &sp.d_w_low[p], &sp.d_ws_low[p], k1z_n)) return 1;
     }
     if (sp.ks_skip) {
         eff.resize((size_t)L.cout * c2 * taps);
@@ -565,7 +584,7 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
             for (int ci = 0; ci < c2; ++ci)
                 memcpy(&eff[((size_t)co * c2 + ci) * taps], &w[((size_t)co * L.cin + c1 + ci) * taps], taps * sizeof(float));
         if (upload_split_weights(ctx, m, *sp.ks_skip, eff.data(), L.cout, c2, &sp.n_cog_skip, &sp.n_chunks_skip,
-                                 &sp.d_w_skip, &sp.d_ws_skip)) return 1;
+                                 &sp.d_w_skip, &sp.d_ws_skip, kz_n)) return 1;
     }
     sp.valid = true;
     return 0;
@@ -581,8 +600,6 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
 // other format has it converted on the device (run_program / slot_as).
 static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
     const int nl = (int)m->layers.size();
-    for (auto& rt : m->layers)
-        if (rt.L.dims != 2) return 0;
     // does layer j read slot `slot` as split cells?  (max-pool: whatever its own consumers read)
     std::vector<int> reads(nl, 0);              // per conv layer: 1 = its (non-image) sources are read as split
     for (int i = 0; i < nl; ++i) {
@@ -591,14 +608,15 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         if (L.op != TPZ_OP_CONV || !rt.ki || rt.ki->cin1) continue;
         if (L.src2 >= 0) {
             if (prepare_split_phases(ctx, m, blob + L.w_off, rt)) return 1;
-            // any other geometry: the same kernel family with the upsample + concat folded into its loader
-            if (rt.ki->epi == EPI_PLAIN && rt.c1 + rt.c2 == L.cin) {
+            // any other geometry (2-D): the same kernel family with the upsample + concat folded into its loader
+            if (L.dims == 2 && rt.ki->epi == EPI_PLAIN && rt.c1 + rt.c2 == L.cin) {
                 rt.ks = pick_split(L.k, L.dil, L.cout, EPI_PLAIN);
                 if (rt.ks && rt.c1 % (8 * rt.ks->CC) != 0) rt.ks = nullptr;
             }
             reads[i] = (rt.sphase.valid || rt.ks) ? 1 : 0;
             continue;
         }
+        if (L.dims == 3 && (rt.ki->epi != EPI_PLAIN || L.dil != 1)) continue;      // plane-stacked 3-D: plain convs only
         rt.ks = pick_split(L.k, L.dil, L.cout, rt.ki->epi);
         if (!rt.ks && rt.ki->epi == EPI_PLAIN) rt.ks = pick_split(L.k, L.dil, L.cout, EPI_PLAIN_F32);
         reads[i] = rt.ks ? 1 : 0;
@@ -624,7 +642,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         if (rt.ki && rt.ki->cin1 && L.src2 < 0) {
             // stem: fp32 MFMA kernel, split store when the consumers read split cells
             if (wanted && L.res < 0 && !L.head && L.post_scale_off < 0 && rt.n_cog == 1)
-                rt.ki_stem_split = find_conv(2, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
+                rt.ki_stem_split = find_conv(L.dims, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
             continue;
         }
         if (rt.ks) {
@@ -637,7 +655,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         }
         if (rt.ks) {
             if (upload_split_weights(ctx, m, *rt.ks, blob + L.w_off, L.cout, L.cin, &rt.s_n_cog, &rt.s_n_chunks,
-                                     &rt.d_wsplit, &rt.d_wscale)) return 1;
+                                     &rt.d_wsplit, &rt.d_wscale, L.dims == 3 ? L.k : 1)) return 1;
             any_split = true;
         }
         if (rt.sphase.valid) any_split = true;
@@ -714,6 +732,8 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
     return launch_mfma(ctx, *ph.ki_skip, a, ph.n_cog_skip, fl);
 }
 
+static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops);
+
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
 static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst,
                           const Slot* s2 = nullptr) {
@@ -755,25 +775,25 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     if (sres) { a.Hres = sres->H; a.Wres = sres->W; a.res_crop = L.res_crop; }
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = L.head ? rt.s_n_cog : 1;
-    a.tiles_x = (dst.W + ks.TW - 1) / ks.TW;
-    a.tiles_y = (dst.H + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
-    a.xcd_swizzle = 1;
-    if (a.tiles_y > 65535) return fail(ctx, "conv grid too large");
-    dim3 grid(a.tiles_x, a.tiles_y, rt.s_n_cog / a.cog_inner);
-    const double flops = 2.0 * L.cout * L.cin * (double)L.k * L.k * (double)dst.H * dst.W;
-    prof_begin(ctx, 0, flops, ks.name);
-    hipError_t e = ks.launch(a, grid, ctx->stream);
-    prof_end(ctx);
-    HIPCHK(ctx, e);
-    return 0;
+    if (L.dims == 3) {
+        a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = 1; a.ooz = 0;
+    }
+    const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
 
 static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops) {
     a.tiles_x = (a.Wout + ks.TW - 1) / ks.TW;
     a.tiles_y = (a.Hout + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
     a.xcd_swizzle = 1;
-    if (a.tiles_y > 65535) return fail(ctx, "conv grid too large");
-    dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
+    if (a.KZ < 1) { a.KZ = 1; a.pad_z = 0; a.Din = a.Dout = a.Dfull = a.Dres = 1; a.ooz = 0; }     // 2-D launch
+    if (a.Dres < 1) a.Dres = 1;
+    a.ncz = n_cog / a.cog_inner;
+    const long long gz = (long long)a.ncz * a.Dout;
+    if (a.tiles_y > 65535 || gz > 65535) return fail(ctx, "conv grid too large");
+    if (a.Din > 1 && (size_t)a.cells_in * a.Din * a.Hin * a.Win * 16 >= ((size_t)1 << 32))
+        return fail(ctx, "3-D tensor too large for the plane-stacked 2xf16 kernel (tile the volume)");
+    dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
     prof_begin(ctx, 0, flops, ks.name);
     hipError_t e = ks.launch(a, grid, ctx->stream);
     prof_end(ctx);
@@ -798,17 +818,17 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.zeros = ctx->d_zeros;
         a.flag = ctx->d_flag;
         a.Cin = a.Cin1 = 1;
-        a.Din = a.D1 = 1; a.Hin = a.H1 = s2.H; a.Win = a.W1 = s2.W;
+        a.Din = a.D1 = s2.D; a.Hin = a.H1 = s2.H; a.Win = a.W1 = s2.W;
         a.cs1 = s2.cs; a.ps1 = s2.ps; a.pitch1 = s2.pitch;
         a.Cout = L.cout;
-        a.Dout = 1; a.Hout = dst.H; a.Wout = dst.W;
+        a.Dout = dst.D; a.Hout = dst.H; a.Wout = dst.W;
         a.pad = a.pad_x = a.pad_y = a.pad_z = L.pad;
         a.os = 1;
-        a.Dfull = 1; a.Hfull = dst.H; a.Wfull = dst.W;
+        a.Dfull = dst.D; a.Hfull = dst.H; a.Wfull = dst.W;
         a.slope = 1.f;
         a.n_chunks = 1;
         a.cog_inner = 1;
-        const double fl = 2.0 * L.cout * (double)L.k * L.k * (double)dst.H * dst.W;
+        const double fl = 2.0 * L.cout * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
         if (launch_mfma(ctx, *sp.ki_skip_stem, a, 1, fl)) return 1;
     } else {
         SplitArgs a;
@@ -827,14 +847,15 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.Hout = dst.H; a.Wout = dst.W;
         a.pad_x = a.pad_y = L.pad;
         a.os = 1; a.Hfull = dst.H; a.Wfull = dst.W;
+        if (L.dims == 3) { a.KZ = L.k; a.pad_z = L.pad; a.Din = s2.D; a.Dout = a.Dfull = dst.D; a.Dres = 1; }
         a.n_chunks = sp.n_chunks_skip;
         a.cog_inner = 1;
-        const double fl = 2.0 * L.cout * ph.c2 * (double)L.k * L.k * (double)dst.H * dst.W;
+        const double fl = 2.0 * L.cout * ph.c2 * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
         if (launch_split(ctx, *sp.ks_skip, a, sp.n_cog_skip, fl)) return 1;
     }
     // ---- one launch per output parity over the low-resolution source, added in place, then the activation
-    for (int p = 0; p < 4; ++p) {
-        const int px = p & 1, py = (p >> 1) & 1;
+    for (int p = 0; p < (1 << L.dims); ++p) {
+        const int px = p & 1, py = (p >> 1) & 1, pz = L.dims == 3 ? (p >> 2) & 1 : 0;
         SplitArgs a;
         memset(&a, 0, sizeof a);
         a.in = reinterpret_cast<const uint4*>(s1.p);
@@ -853,9 +874,13 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.os = 2; a.oox = px; a.ooy = py;
         a.Hfull = dst.H; a.Wfull = dst.W;
         a.Hres = dst.H; a.Wres = dst.W; a.res_crop = 0;
+        if (L.dims == 3) {
+            a.KZ = ph.k1; a.pad_z = phase_pad(L.k, pz); a.Din = s1.D; a.Dout = s1.D; a.ooz = pz;
+            a.Dfull = dst.D; a.Dres = dst.D;
+        }
         a.n_chunks = sp.n_chunks_low;
         a.cog_inner = 1;
-        const double fl = 2.0 * L.cout * ph.c1 * (double)ph.k1 * ph.k1 * (double)s1.H * s1.W;
+        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W;
         if (launch_split(ctx, *sp.ks_low, a, sp.n_cog_low, fl)) return 1;
     }
     return 0;
@@ -865,13 +890,14 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
 static float* slot_as(tpz_ctx* ctx, Slot& s, bool want_split) {
     if (s.split == want_split) return s.p;
     if (s.alt) return s.alt;
-    if (s.D != 1 || s.pitch != s.W || s.ps != (long long)s.H * s.W) return nullptr;
+    if (s.pitch != s.W || s.ps != (long long)s.H * s.W || s.cs != s.ps * s.D) return nullptr;
     const size_t c_alloc = want_split ? split_cells(s.C) * 8 : (size_t)s.C;
-    float* q = (float*)pool_alloc(ctx, c_alloc * s.H * s.W * sizeof(float));
+    float* q = (float*)pool_alloc(ctx, c_alloc * s.D * s.H * s.W * sizeof(float));
     if (!q) return nullptr;
     prof_begin(ctx, 2, 0);
-    hipError_t e = want_split ? launch_to_split(s.p, q, s.C, s.H, s.W, ctx->d_flag, ctx->stream)
-                              : launch_from_split(s.p, q, s.C, s.H, s.W, ctx->stream);
+    // cells are [c/8][D*H*W]: a volume converts as an image of D*H rows
+    hipError_t e = want_split ? launch_to_split(s.p, q, s.C, s.D * s.H, s.W, ctx->d_flag, ctx->stream)
+                              : launch_from_split(s.p, q, s.C, s.D * s.H, s.W, ctx->stream);
     prof_end(ctx);
     if (e != hipSuccess) { pool_release(ctx, q); return nullptr; }
     s.alt = q;
@@ -968,7 +994,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
                 break;
             }
             // which kernels run the layer: the 2xf16 per-parity twin, a 2xf16 kernel, or the fp32 path
-            const bool exact2x = s2 && L.dims == 2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W;
+            const bool exact2x = s2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W && (L.dims == 2 || s2->D == 2 * s1.D);
             const bool use_sphase = split && rt.sphase.valid && exact2x;
             const bool use_split = split && rt.ks && !use_sphase;
             const bool stem_split = split && !use_sphase && !use_split && rt.ki_stem_split;
@@ -1012,7 +1038,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             dst.alt = nullptr;
             dst.owned = (i != nl - 1);
             prof_begin(ctx, 2, 0);
-            hipError_t e = sp ? launch_maxpool2_split(src_p, dst.p, Cs, Hs, Ws, ctx->stream)
+            hipError_t e = sp ? launch_maxpool2_split(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream)
                               : launch_maxpool2(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream);
             prof_end(ctx);
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
@@ -1376,14 +1402,13 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
     return denoise_2d_pass(m, d_in, H, W, patch, pad, d_out, false);
 }
 
-int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
-    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_3d: NULL argument");
+static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out,
+                           bool split) {
     tpz_ctx* ctx = m->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
     if (patch < 1) {
         Slot v;
         set_dense(v, const_cast<float*>(d_in), 1, D, H, W);
-        return denoise_region(m, v, d_out);
+        return denoise_region(m, v, d_out, 1, nullptr, split);
     }
     // global mean / population std (numpy, denoise.py:343)
     float* g = next_nrm(ctx);
@@ -1403,7 +1428,7 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
                 if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
                 Slot tv;
                 set_dense(tv, tile, 1, d, d, d);
-                rc = denoise_region(m, tv, tout, 2, g);
+                rc = denoise_region(m, tv, tout, 2, g, split);
                 if (rc) break;
                 const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
                 prof_begin(ctx, 2, 0);
@@ -1415,6 +1440,22 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
     pool_release(ctx, tile);
     pool_release(ctx, tout);
     return rc;
+}
+
+int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
+    if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_3d: NULL argument");
+    tpz_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (m->split_ok && !ctx->exact) {
+        // 2xf16 path for the whole tomogram; any activation beyond the f16 range re-runs it on the fp32 kernels
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
+        if (denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, true)) return 1;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_flag == 0) { ++m->n_split; return 0; }
+        ++m->n_fallback;
+    }
+    return denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, false);
 }
 
 int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std) {
