@@ -65,7 +65,12 @@ struct SplitArgs {
     int Hres, Wres, res_crop;
     // 3-D mode (KZ >= 1 with tensors [cells][D][H][W]; 2-D: KZ = 1, every D = 1, ncz = grid z).  Single source only.
     int KZ, pad_z, Din, Dout, ooz, Dfull, Dres;
-    int ncz;                  // co-group slices of grid z: blockIdx.z = plane * ncz + co-group slice
+    int ncz;                  // co-group slices of grid z: blockIdx.z = (plane * max(nphase, 1) + phase) * ncz + slice
+    // all output parities of a decoder conv in one launch (runtime.hip prepare_split_phases): phase p = (pz, py, px)
+    // bits uses weights wpk + p * w_phase_bytes, scales wscale + p * Cout, pad (phase_k/2 - parity + 1)/2 and
+    // lattice offset = parity on each axis (pad_* / oo* of the struct are then ignored)
+    int nphase, phase_k;
+    size_t w_phase_bytes;
     int n_chunks;             // chunks of CC (virtual) cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
@@ -162,9 +167,18 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     }
     const int y0 = (by / D) * (C::TH * D) + (by % D);
     const int x0 = bx * C::TW;
-    const int ybase = y0 - a.pad_y, xbase = x0 - a.pad_x;
-    const int oz = (int)blockIdx.z / a.ncz;                  // output plane of the launch lattice (0 in 2-D)
-    const int cogz = (int)blockIdx.z - oz * a.ncz;
+    const int cogz = (int)blockIdx.z % a.ncz;
+    int oz = (int)blockIdx.z / a.ncz;                        // output plane of the launch lattice (0 in 2-D)
+    int pad_x = a.pad_x, pad_y = a.pad_y, pad_z = a.pad_z, oox = a.oox, ooy = a.ooy, ooz = a.ooz, phase = 0;
+    if (a.nphase > 0) {
+        phase = oz % a.nphase;
+        oz /= a.nphase;
+        oox = phase & 1; ooy = (phase >> 1) & 1; ooz = (phase >> 2) & 1;
+        pad_x = (a.phase_k / 2 - oox + 1) / 2;
+        pad_y = (a.phase_k / 2 - ooy + 1) / 2;
+        pad_z = (a.phase_k / 2 - ooz + 1) / 2;
+    }
+    const int ybase = y0 - pad_y, xbase = x0 - pad_x;
     const bool vol = a.KZ > 1 || a.Din > 1;                  // plane-stacked 3-D addressing
 
     constexpr unsigned OOB = 0xffffffffu;
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 // the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
                 const int v = ch * C::CC + g / C::CELL_STRIDE;
                 const int kz = v / a.cells_in, c = v - kz * a.cells_in;
-                const int iz = oz + kz - a.pad_z;
+                const int iz = oz + kz - pad_z;
                 if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
                 else if (off != OOB) off += (unsigned)((((size_t)c * a.Din + iz) * a.Hin) * a.Win * 16);
             }
@@ -258,7 +272,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
         const int cog = cogz * a.cog_inner + cg;
-        const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)cog * w_cog_bytes;
+        const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)phase * a.w_phase_bytes +
+                                    (size_t)cog * w_cog_bytes;
+        const float* wscale = a.wscale + (size_t)phase * a.Cout;
         f32x4 acc[MW][NW];
 #pragma unroll
         for (int m = 0; m < MW; ++m)
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         // all NW pixel fragments are requested back to back before the first is used (the memory latency is
         // paid once per m, not once per fragment), and invalid pixels are handled by clamped addresses +
         // one predicate on the store.
-        const int fz = oz * a.os + a.ooz;                      // output plane in the full tensor (0 in 2-D)
+        const int fz = oz * a.os + ooz;                      // output plane in the full tensor (0 in 2-D)
         const size_t plane_out = (size_t)a.cells_out * a.Dfull * a.Hfull * a.Wfull;
         const size_t plane_res = (size_t)a.cells_out * a.Dres * a.Hres * a.Wres;
         const bool has_bias = a.bias != nullptr;
@@ -348,8 +364,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 okv[n] = oy < a.Hout && ox < a.Wout;
                 if constexpr ((ABL & 1) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
                 const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;   // clamped: loads stay in range
-                fyv[n] = cy * a.os + a.ooy;
-                fxv[n] = cx * a.os + a.oox;
+                fyv[n] = cy * a.os + ooy;
+                fxv[n] = cx * a.os + oox;
             }
         }
 #pragma unroll
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cc = co0 + r < a.Cout ? co0 + r : a.Cout - 1;
-                sc[r] = a.wscale[cc];
+                sc[r] = wscale[cc];
                 bi[r] = has_bias ? a.bias[cc] : 0.f;
                 if constexpr (EPI == EPI_RES_POST) { psc[r] = a.post_scale[cc]; psh[r] = a.post_shift[cc]; }
                 if constexpr (EPI == EPI_HEAD) hw[r] = a.head_w[cc];

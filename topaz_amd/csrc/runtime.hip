@@ -224,8 +224,9 @@ struct LayerRT {
         const SplitKernelInfo* ks_skip = nullptr;      // k-tap kernel over a multi-channel skip source, EPI_PLAIN
         const ConvKernelInfo* ki_skip_stem = nullptr;  // 1-channel skip source: fp32 CIN1 kernel, EPI_SPLIT
         int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
-        void* d_w_low[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        float* d_ws_low[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        void* d_w_low = nullptr;               // the packs of all parities, w_phase_bytes apart
+        float* d_ws_low = nullptr;             // [parity][cout]
+        size_t w_phase_bytes = 0;
         void* d_w_skip = nullptr;
         float* d_ws_skip = nullptr;
     } sphase;
@@ -511,6 +512,9 @@ static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi) {
     return best;
 }
 
+static thread_local std::vector<uint16_t> g_pack_tmp;
+static thread_local std::vector<float> g_inv_tmp;
+
 // kz_n > 1: 3-D weights [cout][cin][kz][k][k] are laid out for the plane-stacked 2-D kernel (conv_split.h): the
 // input channels of plane kz become channels [kz*cells*8, ...) of a 2-D conv with kz_n * cells * 8 input channels
 static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInfo& ks, const float* w, int cout, int cin,
@@ -533,6 +537,11 @@ static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInf
     std::vector<uint16_t> packed;
     std::vector<float> inv;
     pack_weights_split(ks, w, cout, cin, *n_cog, *n_chunks, packed, inv);
+    if (!d_w) {                                  // caller concatenates: hand the host vectors back
+        g_pack_tmp.swap(packed);
+        g_inv_tmp.swap(inv);
+        return 0;
+    }
     float* d = nullptr;
     if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
     *d_w = d;
@@ -560,7 +569,8 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
     }
     const size_t taps = (size_t)kz_n * k * k, taps1 = (size_t)k1z_n * k1 * k1;
     std::vector<double> acc;
-    std::vector<float> eff;
+    std::vector<float> eff, all_s;
+    std::vector<uint16_t> all_w;
     for (int p = 0; p < (1 << dims); ++p) {
         const int px = p & 1, py = (p >> 1) & 1, pz = dims == 3 ? (p >> 2) & 1 : 0;
         acc.assign((size_t)L.cout * c1 * taps1, 0.0);
@@ -576,7 +586,16 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
         eff.resize(acc.size());
         for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
         if (upload_split_weights(ctx, m, *sp.ks_low, eff.data(), L.cout, c1, &sp.n_cog_low, &sp.n_chunks_low,
-                                 &sp.d_w_low[p], &sp.d_ws_low[p], k1z_n)) return 1;
+                                 nullptr, nullptr, k1z_n)) return 1;
+        sp.w_phase_bytes = g_pack_tmp.size() * sizeof(uint16_t);
+        all_w.insert(all_w.end(), g_pack_tmp.begin(), g_pack_tmp.end());
+        all_s.insert(all_s.end(), g_inv_tmp.begin(), g_inv_tmp.end());
+    }
+    {
+        float* d = nullptr;
+        if (upload(ctx, m, reinterpret_cast<const float*>(all_w.data()), (all_w.size() + 1) / 2, &d)) return 1;
+        sp.d_w_low = d;
+        if (upload(ctx, m, all_s.data(), all_s.size(), &sp.d_ws_low)) return 1;
     }
     if (sp.ks_skip) {
         eff.resize((size_t)L.cout * c2 * taps);
@@ -789,7 +808,7 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     if (a.KZ < 1) { a.KZ = 1; a.pad_z = 0; a.Din = a.Dout = a.Dfull = a.Dres = 1; a.ooz = 0; }     // 2-D launch
     if (a.Dres < 1) a.Dres = 1;
     a.ncz = n_cog / a.cog_inner;
-    const long long gz = (long long)a.ncz * a.Dout;
+    const long long gz = (long long)a.ncz * a.Dout * std::max(a.nphase, 1);
     if (a.tiles_y > 65535 || gz > 65535) return fail(ctx, "conv grid too large");
     if (a.Din > 1 && (size_t)a.cells_in * a.Din * a.Hin * a.Win * 16 >= ((size_t)1 << 32))
         return fail(ctx, "3-D tensor too large for the plane-stacked 2xf16 kernel (tile the volume)");
@@ -853,14 +872,16 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         const double fl = 2.0 * L.cout * ph.c2 * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
         if (launch_split(ctx, *sp.ks_skip, a, sp.n_cog_skip, fl)) return 1;
     }
-    // ---- one launch per output parity over the low-resolution source, added in place, then the activation
-    for (int p = 0; p < (1 << L.dims); ++p) {
-        const int px = p & 1, py = (p >> 1) & 1, pz = L.dims == 3 ? (p >> 2) & 1 : 0;
+    // ---- every output parity over the low-resolution source in one launch, added in place, then the activation
+    {
         SplitArgs a;
         memset(&a, 0, sizeof a);
         a.in = reinterpret_cast<const uint4*>(s1.p);
-        a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low[p]);
-        a.wscale = sp.d_ws_low[p];
+        a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low);
+        a.wscale = sp.d_ws_low;
+        a.nphase = 1 << L.dims;
+        a.phase_k = L.k;
+        a.w_phase_bytes = sp.w_phase_bytes;
         a.out = reinterpret_cast<uint4*>(dst.p);
         a.res = reinterpret_cast<const uint4*>(dst.p);
         a.zeros = ctx->d_zeros;
@@ -869,18 +890,15 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.cells_in = a.cells_in1 = (int)split_cells(s1.C);
         a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
         a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
-        a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of this parity
-        a.pad_x = phase_pad(L.k, px); a.pad_y = phase_pad(L.k, py);
-        a.os = 2; a.oox = px; a.ooy = py;
+        a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of one parity
+        a.os = 2;
         a.Hfull = dst.H; a.Wfull = dst.W;
         a.Hres = dst.H; a.Wres = dst.W; a.res_crop = 0;
-        if (L.dims == 3) {
-            a.KZ = ph.k1; a.pad_z = phase_pad(L.k, pz); a.Din = s1.D; a.Dout = s1.D; a.ooz = pz;
-            a.Dfull = dst.D; a.Dres = dst.D;
-        }
+        a.KZ = 1; a.Din = a.Dout = a.Dfull = a.Dres = 1;
+        if (L.dims == 3) { a.KZ = ph.k1; a.Din = s1.D; a.Dout = s1.D; a.Dfull = dst.D; a.Dres = dst.D; }
         a.n_chunks = sp.n_chunks_low;
         a.cog_inner = 1;
-        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W;
+        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W * a.nphase;
         if (launch_split(ctx, *sp.ks_low, a, sp.n_cog_low, fl)) return 1;
     }
     return 0;
