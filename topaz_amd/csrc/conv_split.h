@@ -71,6 +71,10 @@ struct SplitArgs {
     // lattice offset = parity on each axis (pad_* / oo* of the struct are then ignored)
     int nphase, phase_k;
     size_t w_phase_bytes;
+    // or, when every parity reads the same window (5x5 -> 3x3 taps, pad 1): the parities as 4 * Cout VIRTUAL output
+    // channels of one conv (sub-pixel convolution), virtual channel v = parity * Cout + co stored at pixel
+    // (2*oy + py, 2*ox + px), channel co.  subpix_cout = the real Cout (0 = off); wscale has 4 * Cout entries.
+    int subpix_cout;
     int n_chunks;             // chunks of CC (virtual) cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
@@ -370,14 +374,22 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         }
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-            const int co0 = cog * C::MT + m * 16 + l4 * 4;        // 4 consecutive channels: half a cell
+            const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // 4 consecutive (virtual) channels: half a cell
+            int co0 = cov0, sy = 0, sx = 0, n_virt = a.Cout;
+            if (a.subpix_cout > 0) {                               // Cout % 16 == 0: one parity per fragment
+                const int par = cov0 / a.subpix_cout;
+                co0 = cov0 - par * a.subpix_cout;
+                sx = par & 1; sy = (par >> 1) & 1;
+                n_virt = 4 * a.subpix_cout;
+                if (par > 3) co0 = a.Cout;                         // padding fragments of the last co-group
+            }
             const int cell = co0 >> 3, half = (co0 >> 2) & 1;
             const int cellc = cell < a.cells_out ? cell : a.cells_out - 1;
             float sc[4], bi[4], psc[4], psh[4], hw[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cc = co0 + r < a.Cout ? co0 + r : a.Cout - 1;
-                sc[r] = wscale[cc];
+                sc[r] = wscale[cov0 + r < n_virt ? cov0 + r : n_virt - 1];
                 bi[r] = has_bias ? a.bias[cc] : 0.f;
                 if constexpr (EPI == EPI_RES_POST) { psc[r] = a.post_scale[cc]; psh[r] = a.post_shift[cc]; }
                 if constexpr (EPI == EPI_HEAD) hw[r] = a.head_w[cc];
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) {
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
-                    const size_t rc = (((size_t)cellc * a.Dres + fz) * a.Hres + (fyv[n] + a.res_crop)) * a.Wres + (fxv[n] + a.res_crop);
+                    const size_t rc = (((size_t)cellc * a.Dres + fz) * a.Hres + (fyv[n] + sy + a.res_crop)) * a.Wres + (fxv[n] + sx + a.res_crop);
                     const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
                     rh[n] = rp[0];
                     rl[n] = rp[plane_res * 2];
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (okv[n] && co0 + r < a.Cout)
-                            a.out_f32[(((size_t)(co0 + r) * a.Dfull + fz) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]] = v[r];
+                            a.out_f32[(((size_t)(co0 + r) * a.Dfull + fz) * a.Hfull + fyv[n] + sy) * a.Wfull + fxv[n] + sx] = v[r];
                 } else {
                     if (okv[n]) {
 #pragma unroll
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         if (cell < a.cells_out) {
                             uint2 hi, lo;
                             split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + (((size_t)cell * a.Dfull + fz) * a.Hfull + fyv[n]) * a.Wfull + fxv[n]) + half;
+                            uint2* op = reinterpret_cast<uint2*>(a.out + (((size_t)cell * a.Dfull + fz) * a.Hfull + fyv[n] + sy) * a.Wfull + fxv[n] + sx) + half;
                             op[0] = hi;
                             op[plane_out * 2] = lo;
                         }

@@ -3,3 +3,5 @@
 TPZ_SPLIT_RESID(3, 4, 128, 16, 32, 2)
 TPZ_SPLIT_RESID(3, 8, 128, 16, 32, 2)
 TPZ_SPLIT_RESID(3, 2, 128, 16, 32, 2)
+// U-Net dec1.0 (5x5 over a 2x-upsampled source) as one sub-pixel conv: 3x3, 4 x 64 virtual output channels
+TPZ_SPLIT(3, 1, 128, 16, 32, 2, ::tpz::EPI_RES)

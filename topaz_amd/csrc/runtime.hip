@@ -224,6 +224,8 @@ struct LayerRT {
         const SplitKernelInfo* ks_skip = nullptr;      // k-tap kernel over a multi-channel skip source, EPI_PLAIN
         const ConvKernelInfo* ki_skip_stem = nullptr;  // 1-channel skip source: fp32 CIN1 kernel, EPI_SPLIT
         int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
+        const SplitKernelInfo* ks_sub = nullptr;       // 5x5: all parities as 4*cout virtual channels of one 3x3 conv
+        int n_cog_sub = 1;
         void* d_w_low = nullptr;               // the packs of all parities, w_phase_bytes apart
         float* d_ws_low = nullptr;             // [parity][cout]
         size_t w_phase_bytes = 0;
@@ -569,7 +571,7 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
     }
     const size_t taps = (size_t)kz_n * k * k, taps1 = (size_t)k1z_n * k1 * k1;
     std::vector<double> acc;
-    std::vector<float> eff, all_s;
+    std::vector<float> eff, all_s, sub_w;
     std::vector<uint16_t> all_w;
     for (int p = 0; p < (1 << dims); ++p) {
         const int px = p & 1, py = (p >> 1) & 1, pz = dims == 3 ? (p >> 2) & 1 : 0;
@@ -585,13 +587,24 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
                         }
         eff.resize(acc.size());
         for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
+        sub_w.insert(sub_w.end(), eff.begin(), eff.end());          // [parity][cout][c1][taps1]
         if (upload_split_weights(ctx, m, *sp.ks_low, eff.data(), L.cout, c1, &sp.n_cog_low, &sp.n_chunks_low,
                                  nullptr, nullptr, k1z_n)) return 1;
         sp.w_phase_bytes = g_pack_tmp.size() * sizeof(uint16_t);
         all_w.insert(all_w.end(), g_pack_tmp.begin(), g_pack_tmp.end());
         all_s.insert(all_s.end(), g_inv_tmp.begin(), g_inv_tmp.end());
     }
-    {
+    // 5x5 (2-D): both parities of an axis read the same 3-tap window, so the four parity kernels share their B
+    // operand: one conv with 4*cout virtual output channels on the 128-channel tile (conv_split.h subpix_cout)
+    if (dims == 2 && k == 5 && L.cout % 16 == 0) sp.ks_sub = find_split(k1, 1, 128, EPI_RES);
+    if (sp.ks_sub) {
+        all_w.clear(); all_s.clear();
+        int nch = 0;
+        void* dw = nullptr;
+        if (upload_split_weights(ctx, m, *sp.ks_sub, sub_w.data(), 4 * L.cout, c1, &sp.n_cog_sub, &nch, &dw, &sp.d_ws_low)) return 1;
+        sp.d_w_low = dw;
+        sp.n_chunks_low = nch;
+    } else {
         float* d = nullptr;
         if (upload(ctx, m, reinterpret_cast<const float*>(all_w.data()), (all_w.size() + 1) / 2, &d)) return 1;
         sp.d_w_low = d;
@@ -879,9 +892,14 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.in = reinterpret_cast<const uint4*>(s1.p);
         a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low);
         a.wscale = sp.d_ws_low;
-        a.nphase = 1 << L.dims;
-        a.phase_k = L.k;
-        a.w_phase_bytes = sp.w_phase_bytes;
+        if (sp.ks_sub) {
+            a.subpix_cout = L.cout;
+            a.pad_x = a.pad_y = 1;
+        } else {
+            a.nphase = 1 << L.dims;
+            a.phase_k = L.k;
+            a.w_phase_bytes = sp.w_phase_bytes;
+        }
         a.out = reinterpret_cast<uint4*>(dst.p);
         a.res = reinterpret_cast<const uint4*>(dst.p);
         a.zeros = ctx->d_zeros;
@@ -898,8 +916,8 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         if (L.dims == 3) { a.KZ = ph.k1; a.Din = s1.D; a.Dout = s1.D; a.Dfull = dst.D; a.Dres = dst.D; }
         a.n_chunks = sp.n_chunks_low;
         a.cog_inner = 1;
-        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W * a.nphase;
-        if (launch_split(ctx, *sp.ks_low, a, sp.n_cog_low, fl)) return 1;
+        const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W * (1 << L.dims);
+        if (launch_split(ctx, sp.ks_sub ? *sp.ks_sub : *sp.ks_low, a, sp.ks_sub ? sp.n_cog_sub : sp.n_cog_low, fl)) return 1;
     }
     return 0;
 }
