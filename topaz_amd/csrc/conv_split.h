@@ -85,9 +85,11 @@ struct SplitSlot {
     int ky, kx, c;            // ky < 0: padding slot (zero weights)
 };
 
-template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8>
+// K x KX taps (rows x columns; KX = K for the square kernels, KX = 1 for the column kernels that carry the x taps of
+// a stem as input channels or of a 1-output-channel conv as output channels, runtime.hip)
+template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8, int KX_ = K_>
 struct SplitCfg {
-    static constexpr int K = K_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
+    static constexpr int K = K_, KX = KX_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
     // 8 waves: one workgroup per CU (the big dilated tiles need most of the LDS); 4 waves: two per CU, so that
     // one workgroup's prologue / epilogue / barrier waits overlap the other's MFMAs (small-halo, short-K layers)
     static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_, WGS_PER_CU = WAVES_ == 8 ? 1 : 2;
@@ -98,21 +100,21 @@ struct SplitCfg {
     static constexpr int ITH = TH + K - 1;
     // the two 16-byte reads of a ds_read_b128 lane group must be a multiple of 256 B apart: vertically adjacent
     // taps (CC = 1) need rows of a multiple of 16 cells, the two cells of one tap (CC even) only a cell plane of one
-    static constexpr int ITW = (CC == 1) ? (TW + (K - 1) * D + 15) / 16 * 16 : TW + (K - 1) * D;
+    static constexpr int ITW = (CC == 1) ? (TW + (KX - 1) * D + 15) / 16 * 16 : TW + (KX - 1) * D;
     static constexpr int CELL_STRIDE = (ITH * ITW + 15) / 16 * 16;  // cells per 8-channel cell plane
     static constexpr int NPC = CC * CELL_STRIDE;                    // cells per (hi | lo) plane of a chunk
     static constexpr int PLANE_BYTES = NPC * 16;
     static constexpr int IN_BUF = 2 * PLANE_BYTES;
     static constexpr int NR = (NPC + THREADS - 1) / THREADS;        // DMA rounds per plane
     // ---- slots
-    static constexpr bool ROWPAIR = (K == 5) && ((4 * D) % 16 == 0);    // last-row taps kx = 0 and 4 pair up
-    static constexpr int PV = K * (K / 2);                              // vertical tap pairs (CC == 1)
-    static constexpr int PAIRS1 = PV + ((K % 2) ? (ROWPAIR ? K - 1 : K) : 0);
-    static constexpr int NSTEP = (CC == 1) ? (PAIRS1 + 1) / 2 : (K * K * CC + 3) / 4;
+    static constexpr bool ROWPAIR = (K == 5) && (KX == 5) && ((4 * D) % 16 == 0);   // last-row taps kx = 0 and 4 pair up
+    static constexpr int PV = KX * (K / 2);                             // vertical tap pairs (CC == 1)
+    static constexpr int PAIRS1 = PV + ((K % 2) ? (ROWPAIR ? KX - 1 : KX) : 0);
+    static constexpr int NSTEP = (CC == 1) ? (PAIRS1 + 1) / 2 : (K * KX * CC + 3) / 4;
     __host__ __device__ static constexpr SplitSlot slot(int step, int kb) {
         if (CC != 1) {
             const int q = step * 4 + kb, t = q / CC;
-            return t < K * K ? SplitSlot{t / K, t % K, q % CC} : SplitSlot{-1, 0, 0};
+            return t < K * KX ? SplitSlot{t / KX, t % KX, q % CC} : SplitSlot{-1, 0, 0};
         }
         const int p = step * 2 + (kb >> 1), j = kb & 1;
         if (p < PV) return SplitSlot{2 * (p % (K / 2)) + j, p / (K / 2), 0};
@@ -120,9 +122,9 @@ struct SplitCfg {
         if (K % 2 == 0) return SplitSlot{-1, 0, 0};
         if (ROWPAIR) {
             if (e == 0) return SplitSlot{K - 1, j ? 4 : 0, 0};
-            return (e < K - 1 && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
+            return (e < KX - 1 && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
         }
-        return (e < K && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
+        return (e < KX && j == 0) ? SplitSlot{K - 1, e, 0} : SplitSlot{-1, 0, 0};
     }
     __host__ __device__ static constexpr int slot_lds_off(int step, int kb) {
         SplitSlot s = slot(step, kb);

@@ -8,14 +8,14 @@ namespace tpz {
 
 struct SplitKernelInfo {
     int K, D, MT, epi;
-    int TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes;
+    int KX, TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes;
     SplitSlot (*slot)(int step, int kb);
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
     char name[160];
 };
 
 void register_split(const SplitKernelInfo& info);
-const SplitKernelInfo* find_split(int K, int D, int MT, int epi);
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0);    // KX = 0: square (KX == K)
 
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
@@ -37,19 +37,22 @@ template <class C, int EPI>
 struct SplitRegistrar {
     SplitRegistrar() {
         SplitKernelInfo i;
-        i.K = C::K; i.D = C::D; i.MT = C::MT; i.epi = EPI;
+        i.K = C::K; i.KX = C::KX; i.D = C::D; i.MT = C::MT; i.epi = EPI;
         i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.WAVES = C::WAVES; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
         i.lds_bytes = C::LDS_BYTES;
         i.slot = &split_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
-        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.D, i.MT,
-                 i.TH, i.TW, i.CC, i.WAVES, i.epi);
+        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,
+                 i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.epi);
         register_split(i);
     }
 };
 
 #define TPZ_SPLIT(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+// column kernels (K x 1 taps), 4-wave workgroups
+#define TPZ_SPLIT4_COL(K, D, MT, TH, TW, CC, EPI) \
+    static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4, 1>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
 // 4-wave workgroups, two per CU
 #define TPZ_SPLIT4(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);

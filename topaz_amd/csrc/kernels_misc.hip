@@ -417,6 +417,66 @@ hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hi
 }
 
 // ------------------------------------------------------------------------------------------
+// Column-kernel helpers of the 2xf16 path (runtime.hip prepare_split).
+// shiftx_split: out cell jc of pixel (z, y, x) = the 8 values x[z][y][x - pad + 8*jc + j], j = 0..7 (0 outside the
+// image or for taps >= K) as split f16 halves: the kx taps of a 1-channel stem become input channels.
+// shiftsum: out[z][y][x] = sum_v Y[v][z][y][x + v] + bias (then the un-normalisation): the kx taps of a
+// 1-output-channel conv were computed as K virtual output channels over W + 2*pad columns.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restrict__ in, uint4* __restrict__ out,
+                                                           int ncell, int K, int pad, size_t rows, int W, int Wo) {
+    const size_t n = (size_t)ncell * rows * Wo;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo);
+        const size_t t = i / Wo;
+        const size_t row = t % rows;
+        const int jc = (int)(t / rows);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 8 * jc + j, sx = x - pad + tap;
+            v[j] = (tap < K && (unsigned)sx < (unsigned)W) ? in[row * W + sx] : 0.f;
+        }
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        uint2 h0, l0, h1, l1;
+        split4(a, h0, l0);
+        split4(b, h1, l1);
+        out[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[n + i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
+                                                       size_t rows, int W, int Wp, float bias,
+                                                       const float* __restrict__ nrm, int norm_out) {
+    const size_t n = rows * W;
+    float sc = 1.f, sh = 0.f;
+    if (nrm && norm_out) { sc = nrm[2]; sh = nrm[3]; }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t row = i / W;
+        float acc = 0.f;
+        for (int v = 0; v < K; ++v) acc += Y[((size_t)v * rows + row) * Wp + x + v];
+        out[i] = (acc + bias) * sc + sh;
+    }
+}
+
+hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, hipStream_t s) {
+    const int ncell = (K + 7) / 8;
+    const size_t n = (size_t)ncell * rows * Wo;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(shiftx_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, ncell, K, pad, rows, W, Wo);
+    return hipGetLastError();
+}
+hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
+                           int norm_out, hipStream_t s) {
+    const size_t n = rows * W;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // out[c][r] = in[r][c] through a padded 64x64 LDS tile (both sides coalesced)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,

@@ -36,9 +36,10 @@ static std::vector<SplitKernelInfo>& split_registry() {
     return r;
 }
 void register_split(const SplitKernelInfo& info) { split_registry().push_back(info); }
-const SplitKernelInfo* find_split(int K, int D, int MT, int epi) {
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX) {
+    if (KX <= 0) KX = K;
     for (const auto& k : split_registry())
-        if (k.K == K && k.D == D && k.MT == MT && k.epi == epi) return &k;
+        if (k.K == K && k.KX == KX && k.D == D && k.MT == MT && k.epi == epi) return &k;
     return nullptr;
 }
 }  // namespace tpz
@@ -209,12 +210,17 @@ struct LayerRT {
     float* d_post_shift = nullptr;
     float* d_head_w = nullptr;
     float head_b = 0.f;
+    float bias0 = 0.f;                    // bias of output channel 0 (host copy, for the 1-output-channel convs)
     // 2xf16 path (prepare_split): kernel, packed hi/lo weights, per-channel 2^-s; or the stem that feeds it
     const SplitKernelInfo* ks = nullptr;
     const ConvKernelInfo* ki_stem_split = nullptr;
     void* d_wsplit = nullptr;
     float* d_wscale = nullptr;
     int s_n_cog = 1, s_n_chunks = 1;
+    // column-kernel forms (prepare_split): a 1-channel stem as an 8*ncell-channel conv over an x-shifted copy of the
+    // image (kx taps as input channels), a 1-output-channel conv as k virtual output channels + a shifted sum
+    const SplitKernelInfo* ks_stem = nullptr;
+    const SplitKernelInfo* ks_last = nullptr;
     // 2xf16 twin of the phase decomposition: the skip-source part runs first (stem kernel storing split cells
     // when the skip is the 1-channel image, else a plain split kernel), then one split kernel per output parity
     // adds itself in place through the residual epilogue and applies the activation
@@ -438,6 +444,7 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
     }
     if (L.b_off >= 0) {
         if ((size_t)L.b_off + L.cout > n_floats) return fail(ctx, "conv: bias offset out of range");
+        rt.bias0 = blob[L.b_off];
         if (upload(ctx, m, blob + L.b_off, L.cout, &rt.d_bias)) return 1;
     }
     if (L.post_scale_off >= 0) {
@@ -456,8 +463,8 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
 // of f16, scaled per output channel by 2^s (max |w| lands in [2^13, 2^14)) so that the lo halves stay normal.
 static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int cout, int cin, int n_cog, int n_chunks,
                                std::vector<uint16_t>& out, std::vector<float>& wscale_inv) {
-    const int K = ki.K, MW = ki.MT / 16;
-    const size_t taps = (size_t)K * K;
+    const int K = ki.K, KX = ki.KX, MW = ki.MT / 16;
+    const size_t taps = (size_t)K * KX;
     std::vector<float> scale(cout, 1.f);
     wscale_inv.assign(cout, 1.f);
     for (int co = 0; co < cout; ++co) {
@@ -484,7 +491,7 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
                             for (int j = 0; j < 8; ++j) {
                                 const int ci = (ch * ki.CC + sl.c) * 8 + j;
                                 if (ci >= cin) continue;
-                                const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * K + sl.kx] * scale[co];
+                                const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * KX + sl.kx] * scale[co];
                                 const _Float16 hi = (_Float16)v;
                                 const _Float16 lo = (_Float16)(v - (float)hi);
                                 uint16_t hb, lb;
@@ -499,11 +506,11 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
             }
 }
 
-static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi) {
+static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi, int kx = 0) {
     const SplitKernelInfo* best = nullptr;
     int best_padded = 1 << 30;
     for (int mt : MT_CHOICES) {
-        const SplitKernelInfo* c = find_split(k, dil, mt, epi);
+        const SplitKernelInfo* c = find_split(k, dil, mt, epi, kx);
         if (!c) continue;
         const int padded = (cout + mt - 1) / mt * mt;
         if (padded < best_padded || (padded == best_padded && best && mt > best->MT)) {
@@ -524,7 +531,7 @@ static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInf
     std::vector<float> stacked;
     if (kz_n > 1) {
         const int c8 = (int)split_cells(cin) * 8, k = ks.K;
-        const size_t taps2 = (size_t)k * k;
+        const size_t taps2 = (size_t)k * ks.KX;
         stacked.assign((size_t)cout * kz_n * c8 * taps2, 0.f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
@@ -637,6 +644,13 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
     for (int i = 0; i < nl; ++i) {
         LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
+        if (L.op == TPZ_OP_CONV && !rt.ki && L.cout == 1 && L.cin % 8 == 0 && L.src2 < 0 && L.res < 0 && !L.head &&
+            L.post_scale_off < 0 && L.dil == 1 && L.pad == L.k / 2 && L.slope == 1.f && i == nl - 1) {
+            // 1-output-channel last conv: its kx taps as k virtual output channels of a k x 1 column kernel
+            rt.ks_last = find_split(L.k, 1, 16, EPI_PLAIN_F32, 1);
+            reads[i] = rt.ks_last ? 1 : 0;
+            continue;
+        }
         if (L.op != TPZ_OP_CONV || !rt.ki || rt.ki->cin1) continue;
         if (L.src2 >= 0) {
             if (prepare_split_phases(ctx, m, blob + L.w_off, rt)) return 1;
@@ -672,9 +686,39 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         if (L.op != TPZ_OP_CONV) continue;
         const bool wanted = slot_read_split(L.dst);
         if (rt.ki && rt.ki->cin1 && L.src2 < 0) {
-            // stem: fp32 MFMA kernel, split store when the consumers read split cells
-            if (wanted && L.res < 0 && !L.head && L.post_scale_off < 0 && rt.n_cog == 1)
+            if (!(wanted && L.res < 0 && !L.head && L.post_scale_off < 0)) continue;
+            // stem: a k x 1 column kernel over an x-shifted copy of the image (kx taps as 8*ncell input channels) ...
+            if (L.dil == 1) rt.ks_stem = pick_split(L.k, 1, L.cout, EPI_PLAIN, 1);
+            if (rt.ks_stem) {
+                const int k = L.k, kz_n = L.dims == 3 ? k : 1, c8 = (k + 7) / 8 * 8;
+                std::vector<float> w2((size_t)L.cout * c8 * kz_n * k, 0.f);
+                const float* w = blob + L.w_off;                     // [cout][1][kz][ky][kx]
+                for (int co = 0; co < L.cout; ++co)
+                    for (int kz = 0; kz < kz_n; ++kz)
+                        for (int ky = 0; ky < k; ++ky)
+                            for (int kx = 0; kx < k; ++kx)
+                                w2[(((size_t)co * c8 + kx) * kz_n + kz) * k + ky] = w[(((size_t)co * kz_n + kz) * k + ky) * k + kx];
+                if (upload_split_weights(ctx, m, *rt.ks_stem, w2.data(), L.cout, c8, &rt.s_n_cog, &rt.s_n_chunks,
+                                         &rt.d_wsplit, &rt.d_wscale, kz_n)) return 1;
+                any_split = true;
+            } else if (rt.n_cog == 1) {
+                // ... or the fp32 MFMA kernel with a split store
                 rt.ki_stem_split = find_conv(L.dims, L.k, L.dil, rt.ki->MT, true, EPI_SPLIT);
+            }
+            continue;
+        }
+        if (rt.ks_last) {
+            const int k = L.k, kz_n = L.dims == 3 ? k : 1;
+            std::vector<float> w2((size_t)k * L.cin * kz_n * k);
+            const float* w = blob + L.w_off;                         // [1][cin][kz][ky][kx]
+            for (int v = 0; v < k; ++v)
+                for (int ci = 0; ci < L.cin; ++ci)
+                    for (int kz = 0; kz < kz_n; ++kz)
+                        for (int ky = 0; ky < k; ++ky)
+                            w2[(((size_t)v * L.cin + ci) * kz_n + kz) * k + ky] = w[(((size_t)ci * kz_n + kz) * k + ky) * k + v];
+            if (upload_split_weights(ctx, m, *rt.ks_last, w2.data(), k, L.cin, &rt.s_n_cog, &rt.s_n_chunks,
+                                     &rt.d_wsplit, &rt.d_wscale, kz_n)) return 1;
+            any_split = true;
             continue;
         }
         if (rt.ks) {
@@ -922,6 +966,83 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
     return 0;
 }
 
+// 1-channel stem on the 2xf16 path: x-shifted copy of the image (kx taps as channels), then a k x 1 column kernel
+static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst) {
+    const tpz_layer& L = rt.L;
+    const SplitKernelInfo& ks = *rt.ks_stem;
+    if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) return fail(ctx, "2xf16 stem needs a dense input");
+    const int ncell = (L.k + 7) / 8;
+    const size_t rows = (size_t)s1.D * s1.H;
+    float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * dst.W * sizeof(float));
+    if (!X) return fail(ctx, "out of device memory");
+    prof_begin(ctx, 2, 0);
+    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, dst.W, ctx->stream);
+    prof_end(ctx);
+    if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "shiftx failed: %s", hipGetErrorString(e)); }
+    SplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const uint4*>(X);
+    a.wpk = reinterpret_cast<const uint4*>(rt.d_wsplit);
+    a.wscale = rt.d_wscale;
+    a.bias = rt.d_bias;
+    a.out = reinterpret_cast<uint4*>(dst.p);
+    a.zeros = ctx->d_zeros;
+    a.flag = ctx->d_flag;
+    a.slope = L.slope;
+    a.cells_in = a.cells_in1 = ncell;
+    a.Hin = a.H1 = s1.H; a.Win = a.W1 = dst.W;
+    a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
+    a.Hout = dst.H; a.Wout = dst.W;
+    a.pad_x = 0; a.pad_y = L.pad;
+    a.os = 1; a.Hfull = dst.H; a.Wfull = dst.W;
+    if (L.dims == 3) { a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = a.Dfull = dst.D; a.Dres = 1; }
+    a.n_chunks = rt.s_n_chunks;
+    a.cog_inner = 1;
+    const double fl = 2.0 * L.cout * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    const int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
+    pool_release(ctx, X);
+    return rc;
+}
+
+// 1-output-channel last conv on the 2xf16 path: k virtual output channels (one per kx tap) over W + 2*pad columns
+// by a k x 1 column kernel storing fp32, then out[x] = sum_v Y[v][x + v] + bias (and the un-normalisation)
+static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst, const float* d_nrm, int norm_out) {
+    const tpz_layer& L = rt.L;
+    const SplitKernelInfo& ks = *rt.ks_last;
+    const int Wp = dst.W + 2 * L.pad;
+    const size_t rows = (size_t)dst.D * dst.H;
+    float* Y = (float*)pool_alloc(ctx, (size_t)L.k * rows * Wp * sizeof(float));
+    if (!Y) return fail(ctx, "out of device memory");
+    SplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const uint4*>(s1.p);
+    a.wpk = reinterpret_cast<const uint4*>(rt.d_wsplit);
+    a.wscale = rt.d_wscale;
+    a.out_f32 = Y;
+    a.zeros = ctx->d_zeros;
+    a.flag = ctx->d_flag;
+    a.slope = 1.f;
+    a.cells_in = a.cells_in1 = (int)split_cells(s1.C);
+    a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
+    a.Cout = L.k; a.cells_out = 1;
+    a.Hout = dst.H; a.Wout = Wp;
+    a.pad_x = a.pad_y = L.pad;
+    a.os = 1; a.Hfull = dst.H; a.Wfull = Wp;
+    if (L.dims == 3) { a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = a.Dfull = dst.D; a.Dres = 1; }
+    a.n_chunks = rt.s_n_chunks;
+    a.cog_inner = 1;
+    const double fl = 2.0 * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
+    if (!rc) {
+        prof_begin(ctx, 2, 0);
+        hipError_t e = launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream);
+        prof_end(ctx);
+        if (e != hipSuccess) rc = fail(ctx, "shiftsum failed: %s", hipGetErrorString(e));
+    }
+    pool_release(ctx, Y);
+    return rc;
+}
+
 // the slot's 2-D tensor in the wanted format: the producer's own buffer, or a converted copy made once
 static float* slot_as(tpz_ctx* ctx, Slot& s, bool want_split) {
     if (s.split == want_split) return s.p;
@@ -1033,8 +1154,10 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             const bool exact2x = s2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W && (L.dims == 2 || s2->D == 2 * s1.D);
             const bool use_sphase = split && rt.sphase.valid && exact2x;
             const bool use_split = split && rt.ks && !use_sphase;
-            const bool stem_split = split && !use_sphase && !use_split && rt.ki_stem_split;
-            const bool split_dst = use_sphase || stem_split || (use_split && !L.head && rt.ks->epi != EPI_PLAIN_F32);
+            const bool use_stem = split && rt.ks_stem && !s1.split;
+            const bool use_last = split && rt.ks_last;
+            const bool stem_split = split && !use_sphase && !use_split && !use_stem && rt.ki_stem_split;
+            const bool split_dst = use_sphase || stem_split || use_stem || (use_split && !L.head && rt.ks->epi != EPI_PLAIN_F32);
             // split tensors take the bytes of fp32 with the channels rounded up to whole 8-channel cells
             const size_t c_alloc = split_dst ? split_cells(Co) * 8 : (size_t)Co;
             float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
@@ -1045,7 +1168,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             dst.owned = (i != nl - 1);
             if (split_dst && i == nl - 1) { rc = fail(ctx, "layer %d: the result must leave as fp32", i); break; }
             // sources in the format the chosen kernels read (converted once if the producer wrote the other one)
-            const bool want1 = use_sphase || use_split;
+            const bool want1 = use_sphase || use_split || use_last;
             const bool want2 = use_sphase ? !rt.sphase.ki_skip_stem : use_split;
             Slot v1 = s1, v2, vres;
             v1.p = slot_as(ctx, slots[L.src], want1);
@@ -1054,7 +1177,9 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (sres) { vres = *sres; vres.p = slot_as(ctx, slots[L.res], use_split); vres.split = use_split; }
             if (!v1.p || (s2 && !v2.p) || (sres && !vres.p)) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
-            if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
+            if (use_stem) rc = run_stem_split(ctx, rt, v1, dst);
+            else if (use_last) rc = run_last_split(ctx, rt, v1, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
+            else if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
             else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr);
             else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
                                (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
