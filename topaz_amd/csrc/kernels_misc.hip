@@ -424,8 +424,10 @@ hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hi
 // 1-output-channel conv were computed as K virtual output channels over W + 2*pad columns.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restrict__ in, uint4* __restrict__ out,
-                                                           int ncell, int K, int pad, size_t rows, int W, int Wo) {
+                                                           int ncell, int K, int pad, size_t rows, int W, int Wo,
+                                                           unsigned* flag) {
     const size_t n = (size_t)ncell * rows * Wo;
+    bool big = false;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % Wo);
         const size_t t = i / Wo;
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
         for (int j = 0; j < 8; ++j) {
             const int tap = 8 * jc + j, sx = x - pad + tap;
             v[j] = (tap < K && (unsigned)sx < (unsigned)W) ? in[row * W + sx] : 0.f;
+            big |= !(fabsf(v[j]) <= SPLIT_MAX);
         }
         const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
         uint2 h0, l0, h1, l1;
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
         out[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
         out[n + i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
+    if (big && flag) atomicOr(flag, 1u);      // pixel values beyond the f16 range: the caller re-runs in fp32
 }
 
 __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
@@ -461,11 +465,12 @@ __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__
     }
 }
 
-hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, hipStream_t s) {
+hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, unsigned* flag,
+                               hipStream_t s) {
     const int ncell = (K + 7) / 8;
     const size_t n = (size_t)ncell * rows * Wo;
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(shiftx_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, ncell, K, pad, rows, W, Wo);
+    hipLaunchKernelGGL(shiftx_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, ncell, K, pad, rows, W, Wo, flag);
     return hipGetLastError();
 }
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,

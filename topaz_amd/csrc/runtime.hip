@@ -976,7 +976,7 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * dst.W * sizeof(float));
     if (!X) return fail(ctx, "out of device memory");
     prof_begin(ctx, 2, 0);
-    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, dst.W, ctx->stream);
+    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, dst.W, ctx->d_flag, ctx->stream);
     prof_end(ctx);
     if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "shiftx failed: %s", hipGetErrorString(e)); }
     SplitArgs a;
