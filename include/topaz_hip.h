@@ -107,6 +107,16 @@ int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int pat
 /* mean and std of n floats; unbiased != 0 -> divide by n-1 (torch.std), else by n (numpy.std)
  * (topaz/denoise.py:283,343,388).  h_mean_std[2] on the host; synchronises. */
 int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std);
+/* 2-component Gaussian-mixture fit of pixel values, the model behind `topaz normalize` (topaz/stats.py:87-203
+ * norm_fit + gmm_fit with a shared variance and a Beta(alpha, beta) prior on the mixing proportion): for each of
+ * the n_init initialisations (mixing proportion pis[i], hard split at splits[i] = quantile(x, 1 - pis[i]);
+ * pis[i] == 1 selects the single-Gaussian model) runs EM for at most num_iters iterations or until the
+ * log-likelihood gains <= tol, and returns mean / std of the upper component, the MAP proportion and the final
+ * log-likelihood (x scale, the sub-sampling factor).  d_x: n device floats.  One device pass per EM iteration,
+ * statistics in fp64. */
+int tpz_gmm_fit(tpz_ctx* ctx, const float* d_x, size_t n, const double* pis, const double* splits, int n_init,
+                double alpha, double beta, double scale, int num_iters, double tol, double* mus, double* stds,
+                double* pis_out, double* logps);
 /* y = x*scale + shift  (the (x-mu)/std and std*y+mu steps of topaz/denoise.py:389,414) */
 int tpz_affine(tpz_ctx* ctx, const float* d_x, size_t n, float scale, float shift, float* d_y);
 /* 1->1 channel 2-D filter with zero "same" padding: GaussianDenoise / InvGaussianFilter /

@@ -297,6 +297,25 @@ def downsample():
     save('downsample_cases', **out)
 
 
+def normalize():
+    """topaz.stats.normalize (GMM fit, stats.py:37-203) on a bimodal synthetic micrograph: background N(10, 2^2)
+    plus 8 % brighter 'particle' pixels; once on every pixel, once on a seeded random quarter of them."""
+    from topaz.stats import normalize as ref_normalize
+    rs = np.random.RandomState(21)
+    x = (rs.randn(180, 200) * 2 + 10).astype(np.float32)
+    mask = rs.rand(180, 200) < 0.08
+    x[mask] += (4 + rs.randn(int(mask.sum()))).astype(np.float32)
+    for sample, seed in ((1, None), (4, 5)):
+        if seed is not None:
+            np.random.seed(seed)
+        y, md = ref_normalize(x.copy(), alpha=900, beta=1, num_iters=100, sample=sample)
+        save(f'normalize_s{sample}', x=x, y=y, sample=np.asarray(sample), seed=np.asarray(-1 if seed is None else seed),
+             mu=np.asarray(md['mu']), std=np.asarray(md['std']), pi=np.asarray(md['pi']), logp=np.asarray(md['logp']),
+             mus=md['mus'], stds=md['stds'], pis=md['pis'], logps=md['logps'])
+    y, md = ref_normalize(x.copy(), method='affine')
+    save('normalize_affine', x=x, y=y, mu=np.asarray(md['mu']), std=np.asarray(md['std']))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['scoring', 'nms', 'denoise2d', 'denoise3d', 'cli', 'downsample']
     torch.set_num_threads(8)

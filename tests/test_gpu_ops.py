@@ -269,3 +269,52 @@ def test_downsample_4096(gpu_ctx):
     y = downsample(x, 8)
     assert y.shape == (512, 512)
     assert np.abs(y - oracle_downsample(x, 8)).max() <= 1e-4
+
+
+@pytest.mark.parametrize('name', ['normalize_s1', 'normalize_s4'])
+def test_gmm_normalize_vs_oracle_and_reference(gpu_ctx, name):
+    """`topaz normalize`: the mixture fit on the device (tpz_gmm_fit, one fused E-step pass per EM iteration, fp64
+    statistics) against the float64 oracle (same arithmetic: 1e-7) and against the reference's own output."""
+    import os
+    from oracle import stats as ost
+    from topaz_amd import stats as tstats
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', name + '.npz'))
+    x, sample, seed = g['x'], int(g['sample']), int(g['seed'])
+    if sample > 1:
+        np.random.seed(seed)
+    y, md = tstats.normalize(x.copy(), alpha=900, beta=1, num_iters=100, sample=sample)
+    xs, scale = x, 1.0
+    if sample > 1:
+        np.random.seed(seed)
+        n = int(np.round(x.size / sample))
+        scale = x.size / n
+        xs = np.random.choice(x.ravel(), size=n, replace=False)
+    mus, stds, pis, logps = ost.norm_fit(xs, 900, 1, scale=scale)
+    assert np.abs(md['mus'] - mus).max() <= 1e-7 * np.abs(mus).max()
+    assert np.abs(md['stds'] - stds).max() <= 1e-7 * stds.max()
+    assert np.abs(md['pis'] - pis).max() <= 1e-7
+    assert (np.abs(md['logps'] - logps) / np.abs(logps)).max() <= 1e-9
+    assert abs(md['mu'] - float(g['mu'])) <= 1e-5 * abs(float(g['mu'])) and abs(md['std'] - float(g['std'])) <= 1e-5 * float(g['std'])
+    assert np.abs(y - g['y']).max() <= 2e-6
+
+
+def test_normalize_affine_and_cli(gpu_ctx, tmp_path):
+    import json
+    import os
+    from topaz_amd import mrc
+    from topaz_amd import stats as tstats
+    from topaz_amd.main import main as topaz_main
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'normalize_affine.npz'))
+    y, md = tstats.normalize(g['x'].copy(), method='affine')
+    assert np.abs(y - g['y']).max() <= 1e-6 and abs(md['mu'] - float(g['mu'])) <= 1e-6
+    src = tmp_path / 'mic.mrc'
+    with open(src, 'wb') as fh:
+        mrc.write(fh, g['x'][np.newaxis])          # (nz = 1, ny, nx) as utils/image.py save_mrc writes it
+    np.random.seed(3)
+    topaz_main(['normalize', str(src), '-o', str(tmp_path / 'out'), '--sample', '1', '--metadata'])
+    with open(tmp_path / 'out' / 'mic.mrc', 'rb') as fh:
+        out, _, _ = mrc.parse(fh.read())
+    g1 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'normalize_s1.npz'))
+    assert np.abs(np.squeeze(out) - g1['y']).max() <= 2e-6
+    meta = json.load(open(tmp_path / 'out' / 'mic.metadata.json'))
+    assert abs(meta['mu'] - float(g1['mu'])) <= 1e-5 * abs(float(g1['mu'])) and len(meta['mus']) == 12

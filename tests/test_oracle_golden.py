@@ -137,3 +137,27 @@ def test_downsample_golden():
         y = denoising.downsample(z[name + ':x'], int(z[name + ':factor']))
         assert y.shape == z[name + ':y'].shape and y.dtype == z[name + ':y'].dtype
         np.testing.assert_allclose(y, z[name + ':y'], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize('name', ['normalize_s1', 'normalize_s4'])
+def test_normalize_oracle_vs_reference(name):
+    """oracle/stats.py (float64 NumPy) against topaz.stats.normalize run by the reference (float32 torch):
+    all twelve mixture fits, the selected model and the normalised image."""
+    from oracle import stats as ost
+    g = load_golden(name)
+    x, sample, seed = g['x'], int(g['sample']), int(g['seed'])
+    xs, scale = x, 1.0
+    if sample > 1:
+        np.random.seed(seed)
+        n = int(np.round(x.size / sample))
+        scale = x.size / n
+        xs = np.random.choice(x.ravel(), size=n, replace=False)
+    mus, stds, pis, logps = ost.norm_fit(xs, 900, 1, scale=scale)
+    assert np.abs(mus - g['mus']).max() <= 1e-5 * np.abs(g['mus']).max()
+    assert np.abs(stds - g['stds']).max() <= 1e-5 * g['stds'].max()
+    assert np.abs(pis - g['pis']).max() <= 3e-4
+    assert (np.abs(logps - g['logps']) / np.abs(g['logps'])).max() <= 1e-5
+    i = int(np.argmax(logps))
+    assert i == int(np.argmax(g['logps']))
+    y = ((x - mus[i]) / stds[i]).astype(np.float32)
+    assert np.abs(y - g['y']).max() <= 2e-6

@@ -48,6 +48,8 @@ _SIGNATURES = {
     'tpz_denoise_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_denoise_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_mean_std': (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
+    'tpz_gmm_fit': (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
+                              _P, _P, _P, _P]),
     'tpz_affine': (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     'tpz_filter_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
     'tpz_nms_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, C.POINTER(C.c_int)]),

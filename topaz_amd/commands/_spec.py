@@ -1,7 +1,7 @@
 """Flag tables of the hot-path commands.
 
 The flag names, short options, types, defaults and choices are the drop-in surface of the reference CLI
-(topaz/commands/{extract,denoise,denoise3d,segment,downsample}.py); they are kept as data here and the
+(topaz/commands/{extract,denoise,denoise3d,segment,downsample,normalize}.py); they are kept as data here and the
 parsers are generated from them.  Help texts are this project's own wording.  Flags that only make sense
 for training are accepted (so existing command lines keep parsing) and rejected at run time.
 """
@@ -122,6 +122,24 @@ DOWNSAMPLE: List[Flag] = [
     (('-s', '--scale'), dict(type=int, default=4, help='integer reduction factor')),
     (('-o', '--output'), dict(help='file to write')),
     (('-v', '--verbose'), dict(action='store_true', help='report the shapes')),
+]
+
+
+NORMALIZE: List[Flag] = [
+    (('files',), dict(nargs='+')),
+    (('-s', '--scale'), dict(default=1, type=int, help='shrink the images by this factor first')),
+    (('--affine',), dict(action='store_true', help='plain (x - mean) / std of the whole image instead of the mixture fit')),
+    (('--sample',), dict(default=10, type=int, help='fit the mixture on every n-th pixel (random subset)')),
+    (('--niters',), dict(default=100, type=int, help='cap on the EM iterations of one fit')),
+    (('-a', '--alpha'), dict(default=900, type=float, help='alpha of the Beta prior on the mixing proportion')),
+    (('-b', '--beta'), dict(default=1, type=float, help='beta of the Beta prior on the mixing proportion')),
+    (('--metadata',), dict(action='store_true', help='also write <name>.metadata.json with the fitted parameters')),
+    (('-d', '--device'), dict(default=0, type=int, help='GPU to use')),
+    (('-t', '--num-workers'), dict(type=int, default=0, help='accepted for compatibility (the fit runs on the GPU)')),
+    (('-j', '--num-threads'), dict(type=int, default=0, help='accepted for compatibility')),
+    (('-o', '--destdir'), dict(help='directory to write into')),
+    (('--format',), dict(dest='format_', default='mrc', help='comma separated list of mrc, tiff, png')),
+    (('-v', '--verbose'), dict(action='store_true', help='name every processed file')),
 ]
 
 

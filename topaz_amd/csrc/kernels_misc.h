@@ -10,6 +10,8 @@ hipError_t launch_conv_direct(const ConvArgs& a, const float* d_w, int K, int KZ
 hipError_t launch_maxpool2(const float* in, float* out, int C, int D, int H, int W, int dims, hipStream_t s);
 hipError_t launch_meanstd(const float* x, int D, int H, int W, long long ps, int pitch, int unbiased, int mode,
                           const float* d_g, double* d_part, int part_blocks, float* d_out, hipStream_t s);
+hipError_t launch_gmm_pass(const float* x, size_t n, int mode, const double* d_par, double* d_part, int part_blocks,
+                           double* d_out, hipStream_t s);
 hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float shift, hipStream_t s);
 hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, int pitch, const float* d_p, float* y,
                              hipStream_t s);

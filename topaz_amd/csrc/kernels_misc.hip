@@ -417,6 +417,66 @@ hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hi
 }
 
 // ------------------------------------------------------------------------------------------
+// One pass of the 2-component Gaussian-mixture fit behind `topaz normalize` (topaz/stats.py:120-203 gmm_fit).
+// mode 0: hard assignment p1 = (x > split) (the initialisation, stats.py:131-134);
+// mode 1: E-step with the current parameters: log p_k = -(x-mu_k)^2/(2 var_k) - ln(2 pi var_k)/2 + ln(pi_k),
+//         Z = logsumexp, p_k = exp(log p_k - Z).
+// Accumulates, in fp64 and in a fixed order (deterministic), S = {sum Z, sum p0, sum p1, sum p0 x, sum p1 x,
+// sum p0 x^2, sum p1 x^2}: the M-step and the log-likelihood are closed forms of S (runtime.hip gmm_fit).
+// par = {split | mu0, mu1, var0, var1, ln(1-pi), ln(pi)}.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gmm_pass_kernel(const float* __restrict__ x, size_t n, int mode,
+                                                       const double* __restrict__ par, double* __restrict__ part) {
+    __shared__ double sh[4][7];
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const double p0_ = par[0], p1_ = par[1], p2_ = par[2], p3_ = par[3], p4_ = par[4], p5_ = par[5];
+    const double c0 = mode ? -0.5 * log(2.0 * 3.14159265358979323846 * p2_) + p4_ : 0.0;
+    const double c1 = mode ? -0.5 * log(2.0 * 3.14159265358979323846 * p3_) + p5_ : 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        double q0, q1, Z = 0.0;
+        if (mode == 0) {
+            q0 = v <= p0_ ? 1.0 : 0.0;
+            q1 = 1.0 - q0;
+        } else {
+            const double l0 = -(v - p0_) * (v - p0_) / 2.0 / p2_ + c0;
+            const double l1 = -(v - p1_) * (v - p1_) / 2.0 / p3_ + c1;
+            const double ma = l0 > l1 ? l0 : l1;
+            Z = ma + log(exp(l0 - ma) + exp(l1 - ma));
+            q0 = exp(l0 - Z);
+            q1 = exp(l1 - Z);
+        }
+        acc[0] += Z; acc[1] += q0; acc[2] += q1;
+        acc[3] += q0 * v; acc[4] += q1 * v;
+        acc[5] += q0 * v * v; acc[6] += q1 * v * v;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = wave_sum(acc[k]);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) sh[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 7) part[(size_t)blockIdx.x * 7 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void gmm_final_kernel(const double* __restrict__ part, int blocks, double* __restrict__ out) {
+    if (threadIdx.x < 7) {
+        double s = 0.0;
+        for (int b = 0; b < blocks; ++b) s += part[(size_t)b * 7 + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+hipError_t launch_gmm_pass(const float* x, size_t n, int mode, const double* d_par, double* d_part, int part_blocks,
+                           double* d_out, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256 < (size_t)part_blocks ? (n + 255) / 256 : (size_t)part_blocks);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gmm_pass_kernel, dim3(blocks), dim3(256), 0, s, x, n, mode, d_par, d_part);
+    hipLaunchKernelGGL(gmm_final_kernel, dim3(1), dim3(64), 0, s, d_part, blocks, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Column-kernel helpers of the 2xf16 path (runtime.hip prepare_split).
 // shiftx_split: out cell jc of pixel (z, y, x) = the 8 values x[z][y][x - pad + 8*jc + j], j = 0..7 (0 outside the
 // image or for taps >= K) as split f16 halves: the kx taps of a 1-channel stem become input channels.

@@ -353,6 +353,25 @@ def conv_split(x: torch.Tensor, weight, bias=None, dil: int = 1, pad: int = 0, s
     return y, bool(ovf.value)
 
 
+def gmm_fit(x, pis, splits, alpha: float = 900.0, beta: float = 1.0, scale: float = 1.0, num_iters: int = 100,
+            tol: float = 1e-3, ctx: Optional[Context] = None):
+    """tpz_gmm_fit: EM fits of the 2-component pixel mixture for every initialisation (topaz/stats.py:87-203).
+    x: pixel values (any array / device tensor); returns (mus, stds, pis, logps) as float64 arrays."""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    if not torch.is_tensor(x):
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+    x = as_device_f32(x.reshape(-1), ctx)
+    pis = np.ascontiguousarray(np.asarray(pis, dtype=np.float64))
+    splits = np.ascontiguousarray(np.asarray(splits, dtype=np.float64))
+    n = len(pis)
+    outs = [np.zeros(n, dtype=np.float64) for _ in range(4)]
+    check(ctx.lib.tpz_gmm_fit(ctx.handle, _ptr(x), x.numel(), pis.ctypes.data_as(C.c_void_p),
+                              splits.ctypes.data_as(C.c_void_p), n, float(alpha), float(beta), float(scale),
+                              int(num_iters), float(tol), *[o.ctypes.data_as(C.c_void_p) for o in outs]), ctx.handle)
+    return tuple(outs)
+
+
 def maxpool2(x: torch.Tensor, ctx: Optional[Context] = None) -> torch.Tensor:
     ctx = ctx or get_context()
     ctx.bind_current_stream()
