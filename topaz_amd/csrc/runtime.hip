@@ -757,6 +757,9 @@ static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int 
                                  ((ki.TD * ki.TH / 4) * (ki.TW / 16)) * 32 / 8128 / 2);
     }
     if ((long long)a.tiles_y * a.tiles_z > 65535) return fail(ctx, "conv grid too large");
+    // 32-bit LDS-DMA byte offsets relative to the first channel of a chunk
+    if ((size_t)ki.NCH * (size_t)std::max(a.cs1, a.cs2) * 4 >= ((size_t)1 << 32))
+        return fail(ctx, "image too large for one launch: process it in patches");
     dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, n_cog / a.cog_inner);
     prof_begin(ctx, 0, flops, ki.name);
     hipError_t e = ki.launch(a, grid, ctx->stream);
@@ -867,8 +870,12 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     a.ncz = n_cog / a.cog_inner;
     const long long gz = (long long)a.ncz * a.Dout * std::max(a.nphase, 1);
     if (a.tiles_y > 65535 || gz > 65535) return fail(ctx, "conv grid too large");
+    // the LDS-DMA addresses are 32-bit byte offsets from a wave-uniform base: a chunk of cells (2-D) or one half of the
+    // whole tensor (plane-stacked 3-D) must stay below 4 GiB
     if (a.Din > 1 && (size_t)a.cells_in * a.Din * a.Hin * a.Win * 16 >= ((size_t)1 << 32))
         return fail(ctx, "3-D tensor too large for the plane-stacked 2xf16 kernel (tile the volume)");
+    if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32))
+        return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
     dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
     prof_begin(ctx, 0, flops, ks.name);
     hipError_t e = ks.launch(a, grid, ctx->stream);
