@@ -215,6 +215,12 @@ def main():
         other = {name: ctx.prof_get(k)[0] for k, name in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms'))}
         ctx.prof_enable(False)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is the one
+    # measured for exactly this kernel and shape with separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw,
+    # profiles/r01_split_head_pmc.txt); null for any other configuration
+    traffic = None
+    if dom_name.startswith('conv_split_kernel<K=5x5,D=4,MT=128') and args.size == 4096 and args.workload != 'denoise':
+        traffic = 14.6e9 + 2.68e9
     is_split = dom_name.startswith('conv_split')
     peak = SPLIT_PEAK_TFLOPS if is_split else FP32_MFMA_PEAK_TFLOPS
 
@@ -256,7 +262,9 @@ def main():
             # profiled step on the kernel's own stream); `achieved` is algorithmic (fp32-equivalent) FLOP/s
             'roofline': {
                 'bound': 'mfma', 'kernel': dom_name,
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                'traffic_note': 'HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, raw) from profiles/r01_split_head_pmc.txt; '
+                                'algorithmic bytes 8.7e9',
                 'peak_basis': ('f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC (2xf16 split)'
                                if is_split else 'fp32 MFMA peak'),
                 'launches_per_step': dom_n, 'avg_launch_ms': dom_ms / max(1, dom_n),

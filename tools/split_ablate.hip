@@ -64,6 +64,8 @@ int bench(const char* name, int cin, int cout, int H) {
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
     RUN(1, "no epilogue loads/stores");
+    RUN(32, "no residual loads");
+    RUN(64, "no stores");
     RUN(2, "no per-step DMA issue");
     RUN(4, "no per-step barrier");
     RUN(8, "A fragments read once per step");
@@ -79,7 +81,6 @@ int bench(const char* name, int cin, int cout, int H) {
 int main() {
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_RES>("K3 D4 MT128 RES (ResNet8 block2 conv1)", 64, 128, 2048);
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_PLAIN>("K3 D4 MT128 PLAIN", 128, 128, 2048);
-    bench<SplitCfg<5, 4, 128, 16, 32, 2>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
-    bench<SplitCfg<3, 1, 64, 16, 32, 2>, EPI_RES>("K3 D1 MT64 RES (U-Net dec1.0 phase)", 96, 64, 1012);
+    bench<SplitCfg<3, 1, 96, 8, 32, 2, 4>, EPI_PLAIN>("K3 D1 MT96 PLAIN 4-wave (U-Net dec2.2)", 96, 96, 1012);
     return 0;
 }

@@ -149,7 +149,7 @@ struct SplitCfg {
 enum { EPI_PLAIN_F32 = 5 };
 // ABL: timing-ablation switches for tools/split_ablate.hip only (production kernels use ABL = 0; results are not
 // meaningful otherwise):  1 no epilogue loads / stores   2 no per-step DMA issue   4 no per-step barrier
-//   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs
+//   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs   32 no residual loads   64 no stores
 template <class C, int EPI, int ABL = 0>
 __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 if constexpr (EPI == EPI_HEAD) hw[r] = a.head_w[cc];
             }
             uint2 rh[NW], rl[NW];
-            if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) {
+            if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) {
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
                     const size_t rc = (((size_t)cellc * a.Dres + fz) * a.Hres + (fyv[n] + sy + a.res_crop)) * a.Wres + (fxv[n] + sx + a.res_crop);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             for (int n = 0; n < NW; ++n) {
                 float v[4];
                 float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1)) join4(rh[n], rl[n], rv);
+                if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) join4(rh[n], rl[n], rv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[m][n][r] * sc[r] + bi[r];
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         if (okv[n] && co0 + r < a.Cout)
                             a.out_f32[(((size_t)(co0 + r) * a.Dfull + fz) * a.Hfull + fyv[n] + sy) * a.Wfull + fxv[n] + sx] = v[r];
                 } else {
-                    if (okv[n]) {
+                    if (okv[n] && (!(ABL & 64) || a.slope == 12345.f)) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
                         if (cell < a.cells_out) {
