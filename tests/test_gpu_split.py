@@ -219,3 +219,18 @@ def test_unet3d_on_split_path_matches_oracle(gpu_ctx):
     finally:
         gpu_ctx.set_exact(False)
     assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+
+
+@pytest.mark.parametrize('nf,bw,tw', [(24, 7, 3), (40, 11, 5)])
+def test_unet_odd_widths_mixed_paths(gpu_ctx, nf, bw, tw):
+    """Filter counts without a full set of 2xf16 instantiations: layers that have a kernel run split, the others
+    fp32, with on-device format conversion between them (cells of 8 channels, zero-padded) -- results still match."""
+    from oracle import denoising as oden
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(30 + nf, nf=nf, base_width=bw, top_width=tw)
+    dn = Denoise(DenoiseNet('unet', sd))
+    x = np.random.RandomState(nf).randn(192, 160).astype(np.float32)
+    ref = oden.denoise('unet', sd, x)
+    y = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
+    assert _err(y, ref) <= 1e-4
