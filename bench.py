@@ -42,20 +42,15 @@ SPLIT_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 
 
 def build_models(workload: str):
-    from oracle import denoising as oden          # seeded-weight generators only (not on the timed path)
-    from oracle import scoring as oscoring
+    from tools import synth_weights as sw         # seeded NumPy weights; nothing under oracle/ is touched here
     from topaz_amd.denoise import Denoise
     from topaz_amd.denoising.models import DenoiseNet
-    from topaz_amd.model.classifier import LinearClassifier
     out = {}
     if workload in ('pipeline', 'denoise'):
-        sd_d = oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)
+        sd_d = sw.unet_sd(11, nf=48, base_width=11, top_width=5)
         out['denoise'] = (Denoise(DenoiseNet('unet', sd_d)), sd_d)
     if workload in ('pipeline', 'extract'):
-        sd_s = oscoring.synthetic_resnet_sd('resnet8', 64, seed=7)
-        m = LinearClassifier('resnet8', sd_s)
-        m.eval(); m.fill(); m.cuda()
-        out['score'] = (m, sd_s)
+        out['score'] = sw.hip_resnet('resnet8', 64, seed=7)      # head calibrated with the HIP path's own logits
     return out
 
 

@@ -184,31 +184,12 @@ def gaussian_kernel(sigma: float, scale: float = 5, dims: int = 2) -> np.ndarray
 
 
 # ---------------------------------------------------------------------------------------------
-# seeded synthetic weights (architectures whose pretrained blobs are absent)
+# seeded synthetic weights (architectures whose pretrained blobs are absent): tools/synth_weights.py
 # ---------------------------------------------------------------------------------------------
 def synthetic_unet_sd(seed: int, nf: int = 48, base_width: int = 11, top_width: int = 5, depth: int = 5,
                       dims: int = 2) -> 'OrderedDict[str, np.ndarray]':
-    rs = np.random.RandomState(seed)
-    sd = OrderedDict()
-
-    def conv(name, co, ci, k):
-        shape = (co, ci) + (k,) * dims
-        fan = ci * k ** dims
-        sd[name + '.weight'] = (rs.randn(*shape) * np.sqrt(1.6 / fan)).astype(np.float32)
-        sd[name + '.bias'] = (rs.randn(co) * 0.05).astype(np.float32)
-
-    conv('enc1.0', nf, 1, base_width)
-    for i in range(2, depth + 2):
-        conv(f'enc{i}.0', nf, nf, 3)
-    conv(f'dec{depth}.0', 2 * nf, 2 * nf, 3)
-    conv(f'dec{depth}.2', 2 * nf, 2 * nf, 3)
-    for lvl in range(depth - 1, 1, -1):
-        conv(f'dec{lvl}.0', 2 * nf, 3 * nf, 3)
-        conv(f'dec{lvl}.2', 2 * nf, 2 * nf, 3)
-    conv('dec1.0', 64, 2 * nf + 1, top_width)
-    conv('dec1.2', 32, 64, top_width)
-    conv('dec1.4', 1, 32, top_width)
-    return sd
+    from tools import synth_weights as sw
+    return sw.unet_sd(seed, nf, base_width, top_width, depth, dims)
 
 
 def downsample(x: np.ndarray, factor=1, shape=None) -> np.ndarray:

@@ -160,76 +160,15 @@ def score(arch: str, sd, x: np.ndarray, num_threads: int = 0) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
-# seeded synthetic weights for architectures whose pretrained blobs are absent
+# seeded synthetic weights for architectures whose pretrained blobs are absent: generated by
+# tools/synth_weights.py (pure NumPy); here the ResNet head is calibrated with this oracle's own forward pass
 # ---------------------------------------------------------------------------------------------
 def synthetic_resnet_sd(arch: str, units: int, seed: int, bn: bool = False) -> 'OrderedDict[str, np.ndarray]':
-    """He-style random weights with the key layout of LinearClassifier(ResNet8/16(units, bn))."""
-    rs = np.random.RandomState(seed)
-    spec = ARCH_SPECS[arch]()
-    sd = OrderedDict()
-
-    def conv(name, co, ci, k, bias):
-        sd[name + '.weight'] = (rs.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
-        if bias:
-            sd[name + '.bias'] = (rs.randn(co) * 0.1).astype(np.float32)
-
-    def bnorm(name, c):
-        sd[name + '.weight'] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
-        sd[name + '.bias'] = (0.1 * rs.randn(c)).astype(np.float32)
-        sd[name + '.running_mean'] = (0.1 * rs.randn(c)).astype(np.float32)
-        sd[name + '.running_var'] = (1.0 + 0.2 * rs.rand(c)).astype(np.float32)
-
-    u = [units, 2 * units, 4 * units]
-    if arch == 'resnet8':
-        chans = [(1, u[0]), (u[0], u[0]), (u[0], u[1]), (u[1], u[1]), (u[1], u[2])]
-    else:
-        chans = [(1, u[0])] + [(u[0], u[0])] * 4 + [(u[0], u[1])] + [(u[1], u[1])] * 2 + [(u[1], u[2])]
-    for i, (m, (ci, co)) in enumerate(zip(spec, chans)):
-        pre = f'features.features.{i}.'
-        if m['type'] == 'basic':
-            conv(pre + 'conv', co, ci, m['k'], not bn)
-            if bn:
-                bnorm(pre + 'bn', co)
-        else:
-            if ci != co:
-                conv(pre + 'proj', co, ci, 1, False)
-            conv(pre + 'conv0', ci, ci, 3, not bn)
-            if bn:
-                bnorm(pre + 'bn0', ci)
-            conv(pre + 'conv1', co, ci, 3, not bn)
-            if bn:
-                bnorm(pre + 'bn1', co)
-    sd['classifier.weight'] = (rs.randn(1, u[2], 1, 1) * np.sqrt(1.0 / u[2])).astype(np.float32)
-    sd['classifier.bias'] = np.asarray([0.0], dtype=np.float32)
-    # calibrate the head so logits on N(0,1) input look like the pretrained nets' (std ~4, mean ~-8,
-    # range about [-20, +5]): the 1e-4 absolute tolerance of BASELINE.json is stated for that range.
-    probe = np.random.RandomState(seed + 1).randn(64, 64).astype(np.float32)
-    y = score(arch, sd, probe)
-    sd['classifier.weight'] = (sd['classifier.weight'] * (4.0 / max(float(y.std()), 1e-6))).astype(np.float32)
-    sd['classifier.bias'] = np.asarray([-8.0 - float(y.mean()) * 4.0 / max(float(y.std()), 1e-6)], dtype=np.float32)
-    return sd
+    from tools import synth_weights as sw
+    sd = sw.resnet_sd_uncalibrated(arch, units, seed, bn)
+    return sw.calibrate_head(sd, score(arch, sd, sw.head_probe(seed)))
 
 
 def synthetic_basic_sd(sizes, units: int, seed: int, bn: bool = True) -> 'OrderedDict[str, np.ndarray]':
-    rs = np.random.RandomState(seed)
-    sd = OrderedDict()
-    idx, ci = 0, 1
-    for k in sizes:
-        sd[f'features.features.{idx}.weight'] = (rs.randn(units, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
-        if not bn:
-            sd[f'features.features.{idx}.bias'] = (rs.randn(units) * 0.1).astype(np.float32)
-        idx += 1
-        if bn:
-            p = f'features.features.{idx}'
-            sd[p + '.weight'] = (1.0 + 0.1 * rs.randn(units)).astype(np.float32)
-            sd[p + '.bias'] = (0.1 * rs.randn(units)).astype(np.float32)
-            sd[p + '.running_mean'] = (0.1 * rs.randn(units)).astype(np.float32)
-            sd[p + '.running_var'] = (1.0 + 0.2 * rs.rand(units)).astype(np.float32)
-            sd[p + '.num_batches_tracked'] = np.asarray(0, dtype=np.int64)
-            idx += 1
-        sd[f'features.features.{idx}.weight'] = np.asarray([0.25 + 0.05 * rs.rand()], dtype=np.float32)
-        idx += 1
-        ci = units
-    sd['classifier.weight'] = (rs.randn(1, units, 1, 1) * np.sqrt(1.0 / units)).astype(np.float32)
-    sd['classifier.bias'] = np.asarray([-1.0], dtype=np.float32)
-    return sd
+    from tools import synth_weights as sw
+    return sw.basic_sd(sizes, units, seed, bn)

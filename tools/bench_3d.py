@@ -8,11 +8,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import denoising as oden  # noqa: E402
+from tools import synth_weights as sw  # noqa: E402
 from topaz_amd.denoise import Denoise3D  # noqa: E402
 from topaz_amd.denoising.models import DenoiseNet  # noqa: E402
 
-d3 = Denoise3D(DenoiseNet('unet-3d', oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
+d3 = Denoise3D(DenoiseNet('unet-3d', sw.unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
 t = torch.from_numpy(np.random.RandomState(2000).randn(96, 192, 192).astype(np.float32)).cuda()   # 1 x 2 x 2 tiles
 d3.model.device_model.denoise_3d(t, 96, 48)
 torch.cuda.synchronize()

@@ -10,8 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import denoising as oden  # noqa: E402  (seeded weight generators only)
-from oracle import scoring as oscoring  # noqa: E402
+from tools import synth_weights as sw  # noqa: E402
 from topaz_amd import runtime as rt  # noqa: E402
 from topaz_amd.denoise import Denoise, Denoise3D  # noqa: E402
 from topaz_amd.denoising.models import DenoiseNet  # noqa: E402
@@ -38,16 +37,16 @@ def main():
         m.eval(); m.fill(); m.cuda()
         return lambda: rt.nms(m(x[None, None])[0, 0], 14, -6.0)
 
-    rows.append(('C2 extract resnet8 u64 (seeded) + NMS', timed(scorer(LinearClassifier('resnet8', oscoring.synthetic_resnet_sd('resnet8', 64, 7)))), 44.23))
+    rows.append(('C2 extract resnet8 u64 (seeded) + NMS', timed(scorer(sw.hip_resnet('resnet8', 64, 7)[0])), 44.23))
     rows.append(('C2 extract resnet8_u32 (pretrained) + NMS', timed(scorer(load_model('resnet8_u32'))), 11.09))
-    rows.append(('extract resnet16 u64 (seeded, CLI default) + NMS', timed(scorer(LinearClassifier('resnet16', oscoring.synthetic_resnet_sd('resnet16', 64, 7)))), 61.99))
-    rows.append(('extract conv127 u32 (seeded) + NMS', timed(scorer(LinearClassifier('conv127', oscoring.synthetic_basic_sd((7, 5, 5, 5, 5), 32, 7)))), 3.61))
-    dn = Denoise(DenoiseNet('unet', oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)))
+    rows.append(('extract resnet16 u64 (seeded, CLI default) + NMS', timed(scorer(sw.hip_resnet('resnet16', 64, 7)[0])), 61.99))
+    rows.append(('extract conv127 u32 (seeded) + NMS', timed(scorer(LinearClassifier('conv127', sw.basic_sd((7, 5, 5, 5, 5), 32, 7)))), 3.61))
+    dn = Denoise(DenoiseNet('unet', sw.unet_sd(11, nf=48, base_width=11, top_width=5)))
     rows.append(('C3 denoise unet b11/t5 (seeded), -s 1024 -p 500', timed(lambda: dn.denoise_device(x, 1024, 500)), 29.06))
     rows.append(('C3 denoise unet b11/t5 (seeded), whole image', timed(lambda: dn.denoise_device(x, -1, 0)), 9.68))
     d21 = Denoise('unet-v0.2.1')
     rows.append(('C3 denoise unet-v0.2.1 (pretrained), -s 1024 -p 500', timed(lambda: d21.denoise_device(x, 1024, 500)), None))
-    d3 = Denoise3D(DenoiseNet('unet-3d', oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
+    d3 = Denoise3D(DenoiseNet('unet-3d', sw.unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
     t = torch.from_numpy(np.random.RandomState(2000).randn(256, 512, 512).astype(np.float32)).cuda()
     rows.append(('C5 denoise3d unet-3d nf48 (seeded) 512x512x256, 96/48 tiles', timed(lambda: d3.model.device_model.denoise_3d(t, 96, 48), 1), 516.7))
     print(f'{"config":<62} {"ms":>10} {"alg. TFLOP":>11} {"TFLOP/s":>9}')

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import scoring as oscoring  # noqa: E402  (seeded weight generator only)
+from tools import synth_weights as sw  # noqa: E402
 from topaz_amd import runtime as rt  # noqa: E402
 from topaz_amd.model.classifier import LinearClassifier  # noqa: E402
 
@@ -16,7 +16,7 @@ from topaz_amd.model.classifier import LinearClassifier  # noqa: E402
 def main(arch='resnet8', size=4096):
     ctx = rt.get_context(0)
     x = torch.from_numpy(np.random.RandomState(1000).randn(size, size).astype(np.float32)).cuda()
-    m = LinearClassifier(arch, oscoring.synthetic_resnet_sd(arch, 64, 7))
+    m = sw.hip_resnet(arch, 64, 7)[0]
     m.eval(); m.fill(); m.cuda()
     outs = {}
     for exact in (True, False):

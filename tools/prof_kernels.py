@@ -8,8 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import denoising as oden  # noqa: E402  (seeded weight generators only)
-from oracle import scoring as oscoring  # noqa: E402
+from tools import synth_weights as sw  # noqa: E402
 from topaz_amd import runtime as rt  # noqa: E402
 from topaz_amd.denoise import Denoise, Denoise3D  # noqa: E402
 from topaz_amd.denoising.models import DenoiseNet  # noqa: E402
@@ -20,15 +19,15 @@ def main(what):
     ctx = rt.get_context(0)
     if what == 'denoise':
         x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
-        dn = Denoise(DenoiseNet('unet', oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)))
+        dn = Denoise(DenoiseNet('unet', sw.unet_sd(11, nf=48, base_width=11, top_width=5)))
         fn = lambda: dn.denoise_device(x, 1024, 500)
     elif what == 'extract':
         x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
-        m = LinearClassifier('resnet8', oscoring.synthetic_resnet_sd('resnet8', 64, 7))
+        m = sw.hip_resnet('resnet8', 64, 7)[0]
         m.eval(); m.fill(); m.cuda()
         fn = lambda: rt.nms(m(x[None, None])[0, 0], 14, -6.0)
     else:
-        d3 = Denoise3D(DenoiseNet('unet-3d', oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
+        d3 = Denoise3D(DenoiseNet('unet-3d', sw.unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
         t = torch.from_numpy(np.random.RandomState(2000).randn(192, 192, 384).astype(np.float32)).cuda()
         fn = lambda: d3.model.device_model.denoise_3d(t, 96, 48)
     fn()

@@ -1,0 +1,139 @@
+"""Seeded synthetic weights with the state_dict key layout of the reference's architectures, for the networks whose
+pretrained blobs are missing upstream: ResNet8/16 (64 units), conv127/63/31, the U-Nets.
+
+Pure NumPy data generation -- no model evaluation here.  `bench.py` and `tools/*.py` take their weights from this
+module (and calibrate the ResNet head with a forward pass of the HIP path itself); `oracle/` re-exports the same
+generators for the tests, calibrating with the oracle's forward pass."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+# module kinds / kernel sizes of the feature stacks (topaz/model/features/resnet.py:293-302, 322-335)
+RESNET_LAYOUT = {
+    'resnet8': [('basic', 7), ('resid', 3), ('resid', 3), ('resid', 3), ('basic', 5)],
+    'resnet16': [('basic', 7)] + [('resid', 3)] * 7 + [('basic', 5)],
+}
+
+
+def resnet_sd_uncalibrated(arch: str, units: int, seed: int, bn: bool = False) -> 'OrderedDict[str, np.ndarray]':
+    """He-style random weights with the key layout of LinearClassifier(ResNet8/16(units, bn)); unit-scale 1x1 head."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+
+    def conv(name, co, ci, k, bias):
+        sd[name + '.weight'] = (rs.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        if bias:
+            sd[name + '.bias'] = (rs.randn(co) * 0.1).astype(np.float32)
+
+    def bnorm(name, c):
+        sd[name + '.weight'] = (1.0 + 0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.bias'] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.running_mean'] = (0.1 * rs.randn(c)).astype(np.float32)
+        sd[name + '.running_var'] = (1.0 + 0.2 * rs.rand(c)).astype(np.float32)
+
+    u = [units, 2 * units, 4 * units]
+    if arch == 'resnet8':
+        chans = [(1, u[0]), (u[0], u[0]), (u[0], u[1]), (u[1], u[1]), (u[1], u[2])]
+    else:
+        chans = [(1, u[0])] + [(u[0], u[0])] * 4 + [(u[0], u[1])] + [(u[1], u[1])] * 2 + [(u[1], u[2])]
+    for i, ((kind, k), (ci, co)) in enumerate(zip(RESNET_LAYOUT[arch], chans)):
+        pre = f'features.features.{i}.'
+        if kind == 'basic':
+            conv(pre + 'conv', co, ci, k, not bn)
+            if bn:
+                bnorm(pre + 'bn', co)
+        else:
+            if ci != co:
+                conv(pre + 'proj', co, ci, 1, False)
+            conv(pre + 'conv0', ci, ci, 3, not bn)
+            if bn:
+                bnorm(pre + 'bn0', ci)
+            conv(pre + 'conv1', co, ci, 3, not bn)
+            if bn:
+                bnorm(pre + 'bn1', co)
+    sd['classifier.weight'] = (rs.randn(1, u[2], 1, 1) * np.sqrt(1.0 / u[2])).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([0.0], dtype=np.float32)
+    return sd
+
+
+def head_probe(seed: int) -> np.ndarray:
+    """the 64x64 N(0,1) image whose logits calibrate the head"""
+    return np.random.RandomState(seed + 1).randn(64, 64).astype(np.float32)
+
+
+def calibrate_head(sd, probe_logits: np.ndarray):
+    """rescale the 1x1 head so that logits on N(0,1) input look like the pretrained nets' (std ~4, mean ~-8, range
+    about [-20, +5]): the 1e-4 absolute tolerance of BASELINE.json is stated for that range.  In place."""
+    y = np.asarray(probe_logits)
+    gain = 4.0 / max(float(y.std()), 1e-6)
+    sd['classifier.weight'] = (sd['classifier.weight'] * gain).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([-8.0 - float(y.mean()) * gain], dtype=np.float32)
+    return sd
+
+
+def basic_sd(sizes, units: int, seed: int, bn: bool = True) -> 'OrderedDict[str, np.ndarray]':
+    """LinearClassifier(basic.BasicConv(sizes, units)) -- conv127/63/31 with BN and one PReLU slope per layer"""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    idx, ci = 0, 1
+    for k in sizes:
+        sd[f'features.features.{idx}.weight'] = (rs.randn(units, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        if not bn:
+            sd[f'features.features.{idx}.bias'] = (rs.randn(units) * 0.1).astype(np.float32)
+        idx += 1
+        if bn:
+            p = f'features.features.{idx}'
+            sd[p + '.weight'] = (1.0 + 0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.bias'] = (0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.running_mean'] = (0.1 * rs.randn(units)).astype(np.float32)
+            sd[p + '.running_var'] = (1.0 + 0.2 * rs.rand(units)).astype(np.float32)
+            sd[p + '.num_batches_tracked'] = np.asarray(0, dtype=np.int64)
+            idx += 1
+        sd[f'features.features.{idx}.weight'] = np.asarray([0.25 + 0.05 * rs.rand()], dtype=np.float32)
+        idx += 1
+        ci = units
+    sd['classifier.weight'] = (rs.randn(1, units, 1, 1) * np.sqrt(1.0 / units)).astype(np.float32)
+    sd['classifier.bias'] = np.asarray([-1.0], dtype=np.float32)
+    return sd
+
+
+def unet_sd(seed: int, nf: int = 48, base_width: int = 11, top_width: int = 5, depth: int = 5,
+            dims: int = 2) -> 'OrderedDict[str, np.ndarray]':
+    """UDenoiseNet / UDenoiseNetSmall / UDenoiseNet3D (denoising/models.py:74-244, 452-564)"""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+
+    def conv(name, co, ci, k):
+        shape = (co, ci) + (k,) * dims
+        fan = ci * k ** dims
+        sd[name + '.weight'] = (rs.randn(*shape) * np.sqrt(1.6 / fan)).astype(np.float32)
+        sd[name + '.bias'] = (rs.randn(co) * 0.05).astype(np.float32)
+
+    conv('enc1.0', nf, 1, base_width)
+    for i in range(2, depth + 2):
+        conv(f'enc{i}.0', nf, nf, 3)
+    conv(f'dec{depth}.0', 2 * nf, 2 * nf, 3)
+    conv(f'dec{depth}.2', 2 * nf, 2 * nf, 3)
+    for lvl in range(depth - 1, 1, -1):
+        conv(f'dec{lvl}.0', 2 * nf, 3 * nf, 3)
+        conv(f'dec{lvl}.2', 2 * nf, 2 * nf, 3)
+    conv('dec1.0', 64, 2 * nf + 1, top_width)
+    conv('dec1.2', 32, 64, top_width)
+    conv('dec1.4', 1, 32, top_width)
+    return sd
+
+
+def hip_resnet(arch: str, units: int, seed: int, bn: bool = False):
+    """(filled LinearClassifier on the current GPU, state_dict): head calibrated with the HIP path's own logits"""
+    import torch
+    from topaz_amd.model.classifier import LinearClassifier
+    sd = resnet_sd_uncalibrated(arch, units, seed, bn)
+    m = LinearClassifier(arch, sd)
+    m.eval(); m.fill(); m.cuda()
+    y = m(torch.from_numpy(head_probe(seed)).cuda()[None, None])[0, 0].cpu().numpy()
+    calibrate_head(sd, y)
+    m = LinearClassifier(arch, sd)
+    m.eval(); m.fill(); m.cuda()
+    return m, sd
