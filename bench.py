@@ -117,7 +117,8 @@ def main():
     ap.add_argument('--radius', type=int, default=14)
     ap.add_argument('--threshold', type=float, default=-6.0)
     ap.add_argument('--cpu-sample', type=int, default=1024)
-    ap.add_argument('--lanes', type=int, default=2, help='micrographs in flight per GPU (host threads / HIP streams)')
+    ap.add_argument('--lanes', type=int, default=1, help='micrographs in flight per GPU (host threads / HIP streams)')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -141,6 +142,7 @@ def main():
     start = threading.Barrier(args.lanes + 1)
     ready = threading.Barrier(args.lanes + 1)
     lane_models, results, errors = [None] * args.lanes, [[] for _ in range(args.lanes)], []
+    lane_stats = [None] * args.lanes       # per-lane HIP-event statistics of the launches of the timed steps
 
     def lane_main(k):
         try:
@@ -151,6 +153,13 @@ def main():
                 for w in range(args.warmup):
                     run_step(lane_models[k], imgs[args.steps + k * args.warmup + w], args)
                 torch.cuda.current_stream().synchronize()
+                lctx = rt.get_context(local_rank)
+                if not args.no_kernel_timing:
+                    # roofline evidence: HIP events around the convolution launches of the TIMED steps (those of
+                    # >= 20 GFLOP: ~170 of ~700 launches per step, > 95 % of the kernel time), recorded on this lane's
+                    # own stream and resolved only after the timed region; costs ~0.4 % of the step
+                    lctx.prof_enable(2)
+                    lctx.prof_reset()
                 ready.wait()
                 start.wait()
                 for i in range(k, args.steps, args.lanes):
@@ -158,6 +167,7 @@ def main():
                     if c is not None:
                         results[k].append((rank + i * world, s, c))
                 torch.cuda.current_stream().synchronize()
+                lane_stats[k] = (lctx, )
         except BaseException as e:          # surface worker failures in the main thread
             errors.append(e)
             for b in (ready, start):
@@ -195,20 +205,33 @@ def main():
     models = lane_models[0]
     rt.set_lane(0)
 
-    # ---- roofline of the dominant kernel class, measured live with HIP events on the kernel's stream
-    with torch.cuda.stream(torch.cuda.Stream(device=dev)):      # not the legacy default stream
-        ctx = get_context(local_rank)
-        run_step(models, imgs[-1], args)
-        torch.cuda.current_stream().synchronize()
-        ctx.prof_enable(True)
-        ctx.prof_reset()
-        run_step(models, imgs[-1], args)
-        torch.cuda.current_stream().synchronize()
-        conv_ms, conv_n, conv_flops = ctx.prof_get(0)
-        dom_name, dom_ms, dom_n, dom_flops = ctx.prof_get_dominant()
-        kernels = ctx.prof_kernels()
-        other = {name: ctx.prof_get(k)[0] for k, name in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms'))}
-        ctx.prof_enable(False)
+    # ---- roofline: per-kernel HIP-event times of the launches of the timed steps (all lanes), per step
+    merged, other, conv_ms, conv_n, conv_flops = {}, {'conv_direct_ms': 0.0, 'elementwise_ms': 0.0, 'nms_ms': 0.0}, 0.0, 0, 0.0
+    if args.no_kernel_timing:
+        # no events in the timed region: time one extra step on its own stream instead
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            c0 = get_context(local_rank)
+            c0.prof_enable(True)
+            c0.prof_reset()
+            run_step(models, imgs[-1], args)
+            torch.cuda.current_stream().synchronize()
+        stat_ctxs, n_prof_steps = [c0], 1
+    else:
+        stat_ctxs, n_prof_steps = [st[0] for st in lane_stats if st], args.steps
+    for c in stat_ctxs:
+        for name, ms, n, fl in c.prof_kernels():
+            m0 = merged.setdefault(name, [0.0, 0, 0.0])
+            m0[0] += ms; m0[1] += n; m0[2] += fl
+        ms, n, fl = c.prof_get(0)
+        conv_ms += ms; conv_n += n; conv_flops += fl
+        for k, key in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms')):
+            other[key] += c.prof_get(k)[0]
+        c.prof_enable(False)
+    kernels = sorted(((nm, v[0] / n_prof_steps, v[1] / n_prof_steps, v[2] / n_prof_steps) for nm, v in merged.items()),
+                     key=lambda r: -r[1])                    # (name, ms per step, launches per step, FLOP per step)
+    conv_ms, conv_n, conv_flops = conv_ms / n_prof_steps, conv_n / n_prof_steps, conv_flops / n_prof_steps
+    other = {k: v / n_prof_steps for k, v in other.items()}
+    dom_name, dom_ms, dom_n, dom_flops = kernels[0] if kernels else ('', 0.0, 0, 0.0)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is the one
     # measured for exactly this kernel and shape with separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw,
@@ -262,14 +285,18 @@ def main():
                                 'algorithmic bytes 8.7e9',
                 'peak_basis': ('f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC (2xf16 split)'
                                if is_split else 'fp32 MFMA peak'),
-                'launches_per_step': dom_n, 'avg_launch_ms': dom_ms / max(1, dom_n),
-                'algorithmic_tflop_per_launch': dom_flops / max(1, dom_n) / 1e12,
+                'launches_per_step': dom_n, 'avg_launch_ms': dom_ms / max(1e-9, dom_n),
+                'timed_over': ('the timed steps themselves (HIP events on each lane\'s stream)' if not args.no_kernel_timing
+                               else 'one extra step after the timed region'),
+                'algorithmic_tflop_per_launch': dom_flops / max(1e-9, dom_n) / 1e12,
                 'share_of_step': dom_ms / (1e3 * dt / args.steps) if dt > 0 else None,
                 'class_conv_mfma_fp32': cls_f32, 'class_conv_split_2xf16': cls_split,
                 'conv_kernel_ms_per_step': conv_ms, 'conv_algorithmic_tflop_per_step': conv_flops / 1e12,
                 'top_kernels': [{'kernel': k[0], 'ms': k[1], 'launches': k[2], 'tflops': k[3] / k[1] / 1e9}
                                 for k in kernels[:6]],
-                **other,
+                **({} if not args.no_kernel_timing else other),
+                'coverage': ('convolution launches of >= 20 GFLOP (the rest, elementwise and NMS kernels are not timed inside '
+                             'the timed region)' if not args.no_kernel_timing else 'every launch of one extra step'),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

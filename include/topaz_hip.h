@@ -170,7 +170,8 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
 
 /* time (ms, HIP events on the ctx stream) and launch count of the kernels of one class since
  * the last reset.  cls: 0 = conv_mfma, 1 = conv_direct, 2 = elementwise, 3 = nms.
- * Timing is only collected while enabled (it adds two event records per launch). */
+ * Timing is only collected while enabled (it adds two event records per timed launch): on = 1 times every launch,
+ * on = 2 only the convolution launches of >= 20 GFLOP (cheap enough to stay enabled during a benchmark's timed steps). */
 int tpz_prof_enable(tpz_ctx* ctx, int on);
 int tpz_prof_reset(tpz_ctx* ctx);
 int tpz_prof_get(tpz_ctx* ctx, int cls, double* ms, long long* launches, double* flops);

@@ -84,7 +84,8 @@ struct tpz_ctx {
     unsigned* h_flag = nullptr;   // pinned copy
     bool exact = g_exact_fp32;    // fp32 kernels only
     // profiling
-    bool prof = false;
+    int prof = 0;                 // 0 off, 1 every launch, 2 conv launches of >= 20 GFLOP only (cheap enough for timed runs)
+    bool prof_open = false;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> free_events;
     std::vector<std::pair<const void*, ProfAcc>> per_kernel;   // conv_mfma instantiations
@@ -154,7 +155,10 @@ static float* next_nrm(tpz_ctx* ctx) {
 
 // ---- profiling helpers
 static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nullptr) {
+    ctx->prof_open = false;
     if (!ctx->prof) return;
+    if (ctx->prof == 2 && (cls != 0 || flops < 2e10)) return;
+    ctx->prof_open = true;
     ProfRec r;
     r.cls = cls;
     r.flops = flops;
@@ -171,7 +175,8 @@ static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nu
     ctx->recs.push_back(r);
 }
 static void prof_end(tpz_ctx* ctx) {
-    if (!ctx->prof || ctx->recs.empty()) return;
+    if (!ctx->prof_open || ctx->recs.empty()) return;
+    ctx->prof_open = false;
     (void)hipEventRecord(ctx->recs.back().e1, ctx->stream);
 }
 static void prof_flush(tpz_ctx* ctx) {
@@ -1921,7 +1926,7 @@ int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, f
 int tpz_prof_enable(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     prof_flush(ctx);
-    ctx->prof = on != 0;
+    ctx->prof = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return 0;
 }
 int tpz_prof_reset(tpz_ctx* ctx) {

@@ -59,8 +59,9 @@ class Context:
         return torch.device('cuda', self.device)
 
     # ---- profiling counters (HIP events around every launch of a kernel class)
-    def prof_enable(self, on: bool = True) -> None:
-        check(self.lib.tpz_prof_enable(self.handle, 1 if on else 0), self.handle)
+    def prof_enable(self, on=True) -> None:
+        """True / 1: time every launch; 2: only convolution launches of >= 20 GFLOP; False / 0: off"""
+        check(self.lib.tpz_prof_enable(self.handle, int(on)), self.handle)
 
     def prof_reset(self) -> None:
         check(self.lib.tpz_prof_reset(self.handle), self.handle)
