@@ -146,7 +146,10 @@ struct SplitCfg {
 
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
 // EPI_PLAIN_F32 = plain epilogue storing fp32 planes, for a layer whose consumer is not on the 2xf16 path.
-enum { EPI_PLAIN_F32 = 5 };
+// EPI_POOL = plain epilogue followed by MaxPool2d(2) (floor): the encoder convs of the U-Nets, whose un-pooled output
+// nobody else reads (denoising/models.py:81-97) -- the 2x2 maximum is taken on the fp32 values in registers (row
+// pairs inside the wave, column pairs across neighbouring lanes) and only the pooled tensor is stored.
+enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 // ABL: timing-ablation switches for tools/split_ablate.hip only (production kernels use ABL = 0; results are not
 // meaningful otherwise):  1 no epilogue loads / stores   2 no per-step DMA issue   4 no per-step barrier
 //   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs   32 no residual loads   64 no stores
@@ -405,6 +408,36 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     rh[n] = rp[0];
                     rl[n] = rp[plane_res * 2];
                 }
+            }
+            if constexpr (EPI == EPI_POOL) {
+                static_assert(EPI != EPI_POOL || (C::RPW % 2 == 0 && C::D == 1), "pooling pairs tile rows inside a wave");
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    if ((n / NFC) % 2 != 0) continue;                 // the even row of each pair handles the pair
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t0 = acc[m][n][r] * sc[r] + bi[r], t1 = acc[m][n + NFC][r] * sc[r] + bi[r];
+                        t0 = t0 > 0.f ? t0 : t0 * a.slope;
+                        t1 = t1 > 0.f ? t1 : t1 * a.slope;
+                        float t = fmaxf(t0, t1);                       // rows y, y + 1
+                        t = fmaxf(t, __shfl_xor(t, 1, 64));            // columns x, x + 1 (neighbouring lanes)
+                        v[r] = co0 + r < a.Cout ? t : 0.f;
+                    }
+                    const int oy = y0 + wave * C::RPW + n / NFC, ox = x0 + (n % NFC) * 16 + l15;
+                    if ((l15 & 1) == 0 && oy + 1 < a.Hout && ox + 1 < a.Wout) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);
+                        if (cell < a.cells_out) {
+                            uint2 hi, lo;
+                            split4(v, hi, lo);
+                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + (oy >> 1)) * a.Wfull + (ox >> 1)) + half;
+                            op[0] = hi;
+                            op[plane_out * 2] = lo;
+                        }
+                    }
+                }
+                continue;
             }
 #pragma unroll
             for (int n = 0; n < NW; ++n) {

@@ -226,6 +226,7 @@ struct LayerRT {
     // image (kx taps as input channels), a 1-output-channel conv as k virtual output channels + a shifted sum
     const SplitKernelInfo* ks_stem = nullptr;
     const SplitKernelInfo* ks_last = nullptr;
+    const SplitKernelInfo* ks_pool = nullptr;  // twin of ks / ks_stem with the following 2x2 max-pool fused (EPI_POOL)
     // 2xf16 twin of the phase decomposition: the skip-source part runs first (stem kernel storing split cells
     // when the skip is the 1-channel image, else a plain split kernel), then one split kernel per output parity
     // adds itself in place through the residual epilogue and applies the activation
@@ -273,6 +274,7 @@ struct Slot {
     bool owned = false;
     bool set = false;
     bool split = false;       // p holds split f16 cells (split_fmt.h) instead of fp32 planes
+    bool pooled = false;      // the producing conv already applied the max-pool that follows it (EPI_POOL)
     float* alt = nullptr;     // the same tensor converted to the other format for a consumer that needs it
 };
 
@@ -741,6 +743,22 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         }
         if (rt.sphase.valid) any_split = true;
     }
+    // conv -> MaxPool2d(2) where nothing else reads the conv's output (the U-Net encoders): pool in the conv's epilogue
+    for (int i = 0; i + 1 < nl; ++i) {
+        LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        if (L.op != TPZ_OP_CONV || L.dims != 2 || L.dil != 1 || L.head || L.res >= 0 || L.post_scale_off >= 0) continue;
+        const SplitKernelInfo* base = rt.ks_stem ? rt.ks_stem : ((rt.ks && L.src2 < 0 && rt.ks->epi == EPI_PLAIN) ? rt.ks : nullptr);
+        if (!base) continue;
+        int readers = 0, pool = -1;
+        for (int j = 0; j < nl; ++j) {
+            const tpz_layer& Lj = m->layers[j].L;
+            if (Lj.src == L.dst || Lj.src2 == L.dst || Lj.res == L.dst) { ++readers; if (Lj.op == TPZ_OP_MAXPOOL2 && Lj.src == L.dst) pool = j; }
+        }
+        if (readers != 1 || pool != i + 1) continue;
+        const SplitKernelInfo* pk = find_split(base->K, base->D, base->MT, EPI_POOL, base->KX);
+        if (pk && pk->CC == base->CC && pk->NSTEP == base->NSTEP && pk->W_STEP_BYTES == base->W_STEP_BYTES) rt.ks_pool = pk;
+    }
     m->split_ok = any_split;
     return 0;
 }
@@ -820,9 +838,9 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
 
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
 static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst,
-                          const Slot* s2 = nullptr) {
+                          const Slot* s2 = nullptr, bool pooled = false) {
     const tpz_layer& L = rt.L;
-    const SplitKernelInfo& ks = *rt.ks;
+    const SplitKernelInfo& ks = pooled ? *rt.ks_pool : *rt.ks;
     SplitArgs a;
     memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const uint4*>(s1.p);
@@ -853,6 +871,11 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.Cout = L.cout;
     a.cells_out = (int)split_cells(L.cout);
     a.Hout = dst.H; a.Wout = dst.W;
+    if (pooled) {          // dst is the pooled tensor; the launch covers the un-pooled conv output
+        const Slot& g = s2 ? *s2 : s1;
+        a.Hout = g.H + 2 * L.pad - L.dil * (L.k - 1);
+        a.Wout = g.W + 2 * L.pad - L.dil * (L.k - 1);
+    }
     a.pad_x = a.pad_y = L.pad;
     a.os = 1;
     a.Hfull = dst.H; a.Wfull = dst.W;
@@ -862,7 +885,7 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     if (L.dims == 3) {
         a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = 1; a.ooz = 0;
     }
-    const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * a.Hout * a.Wout;
     return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
 
@@ -979,16 +1002,18 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
 }
 
 // 1-channel stem on the 2xf16 path: x-shifted copy of the image (kx taps as channels), then a k x 1 column kernel
-static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst) {
+static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst, bool pooled = false) {
     const tpz_layer& L = rt.L;
-    const SplitKernelInfo& ks = *rt.ks_stem;
+    const SplitKernelInfo& ks = pooled ? *rt.ks_pool : *rt.ks_stem;
     if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) return fail(ctx, "2xf16 stem needs a dense input");
     const int ncell = (L.k + 7) / 8;
     const size_t rows = (size_t)s1.D * s1.H;
-    float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * dst.W * sizeof(float));
+    // conv output geometry (dst is the pooled tensor when the max-pool is fused)
+    const int Hc = s1.H + 2 * L.pad - (L.k - 1), Wc = s1.W + 2 * L.pad - (L.k - 1);
+    float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * Wc * sizeof(float));
     if (!X) return fail(ctx, "out of device memory");
     prof_begin(ctx, 2, 0);
-    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, dst.W, ctx->d_flag, ctx->stream);
+    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream);
     prof_end(ctx);
     if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "shiftx failed: %s", hipGetErrorString(e)); }
     SplitArgs a;
@@ -1002,15 +1027,15 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     a.flag = ctx->d_flag;
     a.slope = L.slope;
     a.cells_in = a.cells_in1 = ncell;
-    a.Hin = a.H1 = s1.H; a.Win = a.W1 = dst.W;
+    a.Hin = a.H1 = s1.H; a.Win = a.W1 = Wc;
     a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
-    a.Hout = dst.H; a.Wout = dst.W;
+    a.Hout = Hc; a.Wout = Wc;
     a.pad_x = 0; a.pad_y = L.pad;
     a.os = 1; a.Hfull = dst.H; a.Wfull = dst.W;
     if (L.dims == 3) { a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = a.Dfull = dst.D; a.Dres = 1; }
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = 1;
-    const double fl = 2.0 * L.cout * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    const double fl = 2.0 * L.cout * std::pow((double)L.k, L.dims) * (double)dst.D * Hc * Wc;
     const int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
     pool_release(ctx, X);
     return rc;
@@ -1170,12 +1195,17 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             const bool use_last = split && rt.ks_last;
             const bool stem_split = split && !use_sphase && !use_split && !use_stem && rt.ki_stem_split;
             const bool split_dst = use_sphase || stem_split || use_stem || (use_split && !L.head && rt.ks->epi != EPI_PLAIN_F32);
+            // the max-pool that follows is applied in this conv's epilogue: the slot receives the pooled tensor
+            const bool fuse_pool = rt.ks_pool && (use_stem || (use_split && !s2)) && i + 1 < nl;
+            const int Hd = fuse_pool ? Ho / 2 : Ho, Wd = fuse_pool ? Wo / 2 : Wo;
             // split tensors take the bytes of fp32 with the channels rounded up to whole 8-channel cells
             const size_t c_alloc = split_dst ? split_cells(Co) * 8 : (size_t)Co;
-            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Hd * Wd * sizeof(float));
             if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
-            set_dense(dst, p, Co, Do, Ho, Wo);
+            if (fuse_pool && (Hd < 1 || Wd < 1)) { rc = fail(ctx, "layer %d: input too small to pool", i + 1); break; }
+            set_dense(dst, p, Co, Do, Hd, Wd);
             dst.split = split_dst;
+            dst.pooled = fuse_pool;
             dst.alt = nullptr;
             dst.owned = (i != nl - 1);
             if (split_dst && i == nl - 1) { rc = fail(ctx, "layer %d: the result must leave as fp32", i); break; }
@@ -1189,12 +1219,18 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (sres) { vres = *sres; vres.p = slot_as(ctx, slots[L.res], use_split); vres.split = use_split; }
             if (!v1.p || (s2 && !v2.p) || (sres && !vres.p)) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
-            if (use_stem) rc = run_stem_split(ctx, rt, v1, dst);
+            if (use_stem) rc = run_stem_split(ctx, rt, v1, dst, fuse_pool);
             else if (use_last) rc = run_last_split(ctx, rt, v1, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
             else if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
-            else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr);
+            else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr, fuse_pool);
             else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
                                (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
+        } else if (L.op == TPZ_OP_MAXPOOL2 && s1.pooled) {
+            // already pooled by the producing conv: the slot changes hands
+            dst = s1;
+            dst.pooled = false;
+            slots[L.src].owned = false;
+            slots[L.src].alt = nullptr;
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
             const int Do = L.dims == 3 ? s1.D / 2 : 1, Ho = s1.H / 2, Wo = s1.W / 2;
