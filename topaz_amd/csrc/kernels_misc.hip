@@ -541,6 +541,36 @@ hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W
     return hipGetLastError();
 }
 
+// space-to-depth of a 1-channel image into one split cell per low-resolution pixel: channel j = 2*qy + qx of cell
+// (y, x) is in[2y + qy][2x + qx] (channels 4..7 are zero).  The 1-channel skip source of the U-Net's dec1.0 joins the
+// sub-pixel form of that layer as four more input channels (runtime.hip prepare_split_phases).
+__global__ __launch_bounds__(256) void s2d_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, int h, int w,
+                                                        int W, unsigned* flag) {
+    const size_t n = (size_t)h * w;
+    bool big = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const size_t y = i / w;
+        const float2 r0 = *reinterpret_cast<const float2*>(in + (2 * y) * W + 2 * x);
+        const float2 r1 = *reinterpret_cast<const float2*>(in + (2 * y + 1) * W + 2 * x);
+        const float a[4] = {r0.x, r0.y, r1.x, r1.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) big |= !(fabsf(a[j]) <= SPLIT_MAX);
+        uint2 h0, l0;
+        split4(a, h0, l0);
+        out[i] = make_uint4(h0.x, h0.y, 0u, 0u);
+        out[n + i] = make_uint4(l0.x, l0.y, 0u, 0u);
+    }
+    if (big && flag) atomicOr(flag, 1u);
+}
+
+hipError_t launch_s2d_split(const float* in, void* out, int h, int w, int W, unsigned* flag, hipStream_t s) {
+    const size_t n = (size_t)h * w;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(s2d_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, h, w, W, flag);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // out[c][r] = in[r][c] through a padded 64x64 LDS tile (both sides coalesced)
 // ------------------------------------------------------------------------------------------

@@ -238,6 +238,7 @@ struct LayerRT {
         int n_cog_low = 1, n_chunks_low = 1, n_cog_skip = 1, n_chunks_skip = 1;
         const SplitKernelInfo* ks_sub = nullptr;       // 5x5: all parities as 4*cout virtual channels of one 3x3 conv
         int n_cog_sub = 1;
+        bool sub_with_skip = false;            // ... the 1-channel skip source folded in as 4 space-to-depth channels
         void* d_w_low = nullptr;               // the packs of all parities, w_phase_bytes apart
         float* d_ws_low = nullptr;             // [parity][cout]
         size_t w_phase_bytes = 0;
@@ -611,11 +612,38 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
     // 5x5 (2-D): both parities of an axis read the same 3-tap window, so the four parity kernels share their B
     // operand: one conv with 4*cout virtual output channels on the 128-channel tile (conv_split.h subpix_cout)
     if (dims == 2 && k == 5 && L.cout % 16 == 0) sp.ks_sub = find_split(k1, 1, 128, EPI_RES);
+    if (sp.ks_sub && c2 == 1) {
+        // The 1-channel skip source x joins as 4 space-to-depth channels (s2d_split_kernel): x[2y+qy][2x+qx] is channel
+        // 2*qy+qx of the low-resolution pixel (y, x), and the 5x5 window around output (2oy+py, 2ox+px) lies inside the
+        // same 3x3 low-resolution window: tap (ty, tx) of s2d channel (qy, qx) carries w[ky][kx], ky = 2(ty-1)+qy-py+2.
+        // One plain launch then does the whole layer -- no skip pass, no in-place residual.
+        const SplitKernelInfo* pl = find_split(k1, 1, 128, EPI_PLAIN);
+        if (pl && pl->CC == sp.ks_sub->CC) {
+            const int cin2 = c1 + 8;
+            std::vector<float> w2((size_t)4 * L.cout * cin2 * taps1, 0.f);
+            for (int p = 0; p < 4; ++p)
+                for (int co = 0; co < L.cout; ++co) {
+                    const size_t v = (size_t)p * L.cout + co;
+                    memcpy(&w2[v * cin2 * taps1], &sub_w[v * c1 * taps1], (size_t)c1 * taps1 * sizeof(float));
+                    const int px = p & 1, py = (p >> 1) & 1;
+                    for (int q = 0; q < 4; ++q)
+                        for (int ty = 0; ty < 3; ++ty)
+                            for (int tx = 0; tx < 3; ++tx) {
+                                const int ky = 2 * (ty - 1) + (q >> 1) - py + 2, kx = 2 * (tx - 1) + (q & 1) - px + 2;
+                                if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+                                w2[(v * cin2 + c1 + q) * taps1 + (size_t)ty * 3 + tx] = w[((size_t)co * L.cin + c1) * taps + (size_t)ky * 5 + kx];
+                            }
+                }
+            sub_w.swap(w2);
+            sp.ks_sub = pl;
+            sp.sub_with_skip = true;
+        }
+    }
     if (sp.ks_sub) {
         all_w.clear(); all_s.clear();
         int nch = 0;
         void* dw = nullptr;
-        if (upload_split_weights(ctx, m, *sp.ks_sub, sub_w.data(), 4 * L.cout, c1, &sp.n_cog_sub, &nch, &dw, &sp.d_ws_low)) return 1;
+        if (upload_split_weights(ctx, m, *sp.ks_sub, sub_w.data(), 4 * L.cout, sp.sub_with_skip ? c1 + 8 : c1, &sp.n_cog_sub, &nch, &dw, &sp.d_ws_low)) return 1;
         sp.d_w_low = dw;
         sp.n_chunks_low = nch;
     } else {
@@ -918,6 +946,42 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
     const tpz_layer& L = rt.L;
     const LayerRT::SplitPhase& sp = rt.sphase;
     const LayerRT::Phase& ph = rt.phase;
+    if (sp.sub_with_skip) {
+        // one plain sub-pixel launch: low-resolution source + the space-to-depth copy of the 1-channel skip source
+        if (s2.pitch != s2.W || s2.ps != (long long)s2.H * s2.W) return fail(ctx, "2xf16 decoder needs a dense skip source");
+        float* X = (float*)pool_alloc(ctx, (size_t)8 * s1.H * s1.W * sizeof(float));
+        if (!X) return fail(ctx, "out of device memory");
+        prof_begin(ctx, 2, 0);
+        hipError_t e = launch_s2d_split(s2.p, X, s1.H, s1.W, s2.W, ctx->d_flag, ctx->stream);
+        prof_end(ctx);
+        if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "s2d failed: %s", hipGetErrorString(e)); }
+        SplitArgs a;
+        memset(&a, 0, sizeof a);
+        a.in = reinterpret_cast<const uint4*>(s1.p);
+        a.in2 = reinterpret_cast<const uint4*>(X);
+        a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low);
+        a.wscale = sp.d_ws_low;
+        a.bias = rt.d_bias;
+        a.subpix_cout = L.cout;
+        a.pad_x = a.pad_y = 1;
+        a.out = reinterpret_cast<uint4*>(dst.p);
+        a.zeros = ctx->d_zeros;
+        a.flag = ctx->d_flag;
+        a.slope = L.slope;
+        a.cells_in1 = (int)split_cells(s1.C);
+        a.cells_in = a.cells_in1 + 1;
+        a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
+        a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
+        a.Hout = s1.H; a.Wout = s1.W;
+        a.os = 2;
+        a.Hfull = dst.H; a.Wfull = dst.W;
+        a.n_chunks = sp.n_chunks_low;
+        a.cog_inner = 1;
+        const double fl = 2.0 * L.cout * (ph.c1 * 9.0 * 4.0 + 25.0 * 4.0) * (double)s1.H * s1.W;
+        const int rc = launch_split(ctx, *sp.ks_sub, a, sp.n_cog_sub, fl);
+        pool_release(ctx, X);
+        return rc;
+    }
     // ---- skip-source part over the full grid: bias, no activation
     if (sp.ki_skip_stem) {
         ConvArgs a;
