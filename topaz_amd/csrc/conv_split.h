@@ -63,7 +63,8 @@ struct SplitArgs {
     // of the [Hfull][Wfull] output; the residual is read at the same full-tensor position (+ res_crop)
     int os, ooy, oox, Hfull, Wfull;
     int Hres, Wres, res_crop;
-    // 3-D mode (KZ >= 1 with tensors [cells][D][H][W]; 2-D: KZ = 1, every D = 1, ncz = grid z).  Single source only.
+    // 3-D mode (KZ >= 1 with tensors [cells][D][H][W]; 2-D: KZ = 1, every D = 1, ncz = grid z); `in2` must have the
+    // geometry of `in` there (no upsampling).
     int KZ, pad_z, Din, Dout, ooz, Dfull, Dres;
     int ncz;                  // co-group slices of grid z: blockIdx.z = (plane * max(nphase, 1) + phase) * ncz + slice
     // all output parities of a decoder conv in one launch (runtime.hip prepare_split_phases): phase p = (pz, py, px)
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         }
     };
     // chunks [0, chunks1) read `in`, the rest `in2` (the host guarantees cells_in1 % CC == 0 with a second source)
-    const int chunks1 = a.in2 ? a.cells_in1 / C::CC : a.n_chunks;
+    // (plane-stacked 3-D: the source is chosen per cell in issue_input, chunks never switch)
+    const int chunks1 = (a.in2 && !vol) ? a.cells_in1 / C::CC : a.n_chunks;
     const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1 * (vol ? a.Din : 1);   // cells per plane of `in`
-    const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * a.Hin * a.Win;      // ... of `in2`
+    const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * a.Hin * a.Win * (vol ? a.Din : 1);   // ... of `in2`
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
 
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const void* bhi = uniform_ptr(vol ? a.in : chunk);
             const void* blo = uniform_ptr((vol ? a.in : chunk) + (second ? plane2 : plane1));
             unsigned off = lds_tab[g];
+            bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
             if (!vol) {
                 if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
             } else {
@@ -241,19 +244,27 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int kz = v / a.cells_in, c = v - kz * a.cells_in;
                 const int iz = oz + kz - pad_z;
                 if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
-                else if (off != OOB) off += (unsigned)((((size_t)c * a.Din + iz) * a.Hin) * a.Win * 16);
+                else if (off != OOB) {
+                    lane2 = c >= a.cells_in1;
+                    off += (unsigned)((((size_t)(lane2 ? c - a.cells_in1 : c) * a.Din + iz) * a.Hin) * a.Win * 16);
+                }
             }
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
-            if (!__any(off == OOB)) {
+            if (!__any(off == OOB || lane2)) {
                 glds_b128(off, bhi, dst);
                 glds_b128(off, blo, dst + C::PLANE_BYTES);
             } else {
-                if (off != OOB) {
-                    glds_b128(off, bhi, dst);
-                    glds_b128(off, blo, dst + C::PLANE_BYTES);
-                } else {
+                if (off == OOB) {
                     glds_b128(0u, zsrc, dst);
                     glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
+                } else if (lane2) {
+                    const void* b2 = uniform_ptr(a.in2);
+                    const void* b2lo = uniform_ptr(a.in2 + plane2);
+                    glds_b128(off, b2, dst);
+                    glds_b128(off, b2lo, dst + C::PLANE_BYTES);
+                } else {
+                    glds_b128(off, bhi, dst);
+                    glds_b128(off, blo, dst + C::PLANE_BYTES);
                 }
             }
         }

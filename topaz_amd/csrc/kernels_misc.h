@@ -21,7 +21,8 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
                                hipStream_t s);
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
                            int norm_out, hipStream_t s);
-hipError_t launch_s2d_split(const float* in, void* out, int h, int w, int W, unsigned* flag, hipStream_t s);
+hipError_t launch_s2d_split(const float* in, void* out, int d, int h, int w, int H, int W, int dims, unsigned* flag,
+                            hipStream_t s);
 hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsigned* flag, hipStream_t s);
 hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* dst, long long dps, int dpitch, int bd,

@@ -541,33 +541,43 @@ hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W
     return hipGetLastError();
 }
 
-// space-to-depth of a 1-channel image into one split cell per low-resolution pixel: channel j = 2*qy + qx of cell
-// (y, x) is in[2y + qy][2x + qx] (channels 4..7 are zero).  The 1-channel skip source of the U-Net's dec1.0 joins the
-// sub-pixel form of that layer as four more input channels (runtime.hip prepare_split_phases).
-__global__ __launch_bounds__(256) void s2d_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, int h, int w,
-                                                        int W, unsigned* flag) {
-    const size_t n = (size_t)h * w;
+// space-to-depth of a 1-channel image / volume into one split cell per low-resolution pixel: channel
+// j = (2*qz + qy)*2 + qx of cell (z, y, x) is in[2z + qz][2y + qy][2x + qx] (2-D: qz = 0, channels 4..7 zero).  The
+// 1-channel skip source of a U-Net's dec1.0 joins the per-parity form of that layer as these extra input channels
+// (runtime.hip prepare_split_phases).
+__global__ __launch_bounds__(256) void s2d_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, int d, int h,
+                                                        int w, int H, int W, int dims, unsigned* flag) {
+    const size_t n = (size_t)d * h * w;
     bool big = false;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w);
-        const size_t y = i / w;
-        const float2 r0 = *reinterpret_cast<const float2*>(in + (2 * y) * W + 2 * x);
-        const float2 r1 = *reinterpret_cast<const float2*>(in + (2 * y + 1) * W + 2 * x);
-        const float a[4] = {r0.x, r0.y, r1.x, r1.y};
+        const size_t t = i / w;
+        const size_t y = t % h, z = t / h;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int nz = dims == 3 ? 2 : 1;
+        for (int qz = 0; qz < nz; ++qz) {
+            const float* p = in + (((dims == 3 ? 2 * z + qz : 0) * (size_t)H + 2 * y) * W + 2 * x);
+            const float2 r0 = *reinterpret_cast<const float2*>(p);
+            const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+            v[qz * 4 + 0] = r0.x; v[qz * 4 + 1] = r0.y; v[qz * 4 + 2] = r1.x; v[qz * 4 + 3] = r1.y;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) big |= !(fabsf(a[j]) <= SPLIT_MAX);
-        uint2 h0, l0;
+        for (int j = 0; j < 8; ++j) big |= !(fabsf(v[j]) <= SPLIT_MAX);
+        const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+        uint2 h0, l0, h1, l1;
         split4(a, h0, l0);
-        out[i] = make_uint4(h0.x, h0.y, 0u, 0u);
-        out[n + i] = make_uint4(l0.x, l0.y, 0u, 0u);
+        split4(b, h1, l1);
+        out[i] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[n + i] = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
     if (big && flag) atomicOr(flag, 1u);
 }
 
-hipError_t launch_s2d_split(const float* in, void* out, int h, int w, int W, unsigned* flag, hipStream_t s) {
-    const size_t n = (size_t)h * w;
+hipError_t launch_s2d_split(const float* in, void* out, int d, int h, int w, int H, int W, int dims, unsigned* flag,
+                            hipStream_t s) {
+    const size_t n = (size_t)d * h * w;
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(s2d_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, h, w, W, flag);
+    hipLaunchKernelGGL(s2d_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, d, h, w, H, W, dims, flag);
     return hipGetLastError();
 }
 

@@ -239,6 +239,8 @@ struct LayerRT {
         const SplitKernelInfo* ks_sub = nullptr;       // 5x5: all parities as 4*cout virtual channels of one 3x3 conv
         int n_cog_sub = 1;
         bool sub_with_skip = false;            // ... the 1-channel skip source folded in as 4 space-to-depth channels
+        bool low_with_skip = false;            // 3x3(x3): the same fold into the per-parity kernels (one more cell)
+        const SplitKernelInfo* ks_low_plain = nullptr;
         void* d_w_low = nullptr;               // the packs of all parities, w_phase_bytes apart
         float* d_ws_low = nullptr;             // [parity][cout]
         size_t w_phase_bytes = 0;
@@ -585,6 +587,16 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
         if (!sp.ks_skip) return 0;
     }
     const size_t taps = (size_t)kz_n * k * k, taps1 = (size_t)k1z_n * k1 * k1;
+    // 3x3(x3) with a 1-channel skip source: its space-to-depth cell reads exactly the 2-tap window of each parity, so it
+    // joins every parity kernel as one more input cell (8 channels) and the skip pass + in-place residual disappear
+    if (k == 3 && c2 == 1) {
+        sp.ks_low_plain = find_split(k1, 1, sp.ks_low->MT, EPI_PLAIN);
+        // (2-D: the chunks switch source, so the first source must fill whole chunks; 3-D picks the source per cell)
+        if (sp.ks_low_plain && sp.ks_low_plain->CC == sp.ks_low->CC && sp.ks_low_plain->WAVES == sp.ks_low->WAVES &&
+            (dims == 3 || (c1 / 8) % sp.ks_low_plain->CC == 0))
+            sp.low_with_skip = true;
+    }
+    const int c1e = sp.low_with_skip ? c1 + 8 : c1;
     std::vector<double> acc;
     std::vector<float> eff, all_s, sub_w;
     std::vector<uint16_t> all_w;
@@ -600,11 +612,30 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
                             acc[((size_t)co * c1 + ci) * taps1 + ((size_t)tz * k1 + phase_tap(k, py, ky)) * k1 + phase_tap(k, px, kx)] +=
                                 (double)w[((size_t)co * L.cin + ci) * taps + ((size_t)kz * k + ky) * k + kx];
                         }
-        eff.resize(acc.size());
-        for (size_t i = 0; i < acc.size(); ++i) eff[i] = (float)acc[i];
-        sub_w.insert(sub_w.end(), eff.begin(), eff.end());          // [parity][cout][c1][taps1]
-        if (upload_split_weights(ctx, m, *sp.ks_low, eff.data(), L.cout, c1, &sp.n_cog_low, &sp.n_chunks_low,
-                                 nullptr, nullptr, k1z_n)) return 1;
+        eff.assign((size_t)L.cout * c1e * taps1, 0.f);
+        for (int co = 0; co < L.cout; ++co)
+            for (size_t i = 0; i < (size_t)c1 * taps1; ++i) eff[(size_t)co * c1e * taps1 + i] = (float)acc[(size_t)co * c1 * taps1 + i];
+        if (sp.low_with_skip) {
+            const int nq = 1 << dims;
+            for (int co = 0; co < L.cout; ++co)
+                for (int q = 0; q < nq; ++q) {
+                    const int qx = q & 1, qy = (q >> 1) & 1, qz = dims == 3 ? (q >> 2) & 1 : 0;
+                    for (int tz = 0; tz < k1z_n; ++tz)
+                        for (int ty = 0; ty < k1; ++ty)
+                            for (int tx = 0; tx < k1; ++tx) {
+                                // full-resolution offset of s2d element (q, tap t) from the output voxel of parity p
+                                const int dz = dims == 3 ? 2 * (tz - phase_pad(k, pz)) + qz - pz : 0;
+                                const int dy = 2 * (ty - phase_pad(k, py)) + qy - py, dx = 2 * (tx - phase_pad(k, px)) + qx - px;
+                                if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) continue;
+                                const int kz = dims == 3 ? dz + 1 : 0;
+                                eff[((size_t)co * c1e + c1 + q) * taps1 + ((size_t)tz * k1 + ty) * k1 + tx] =
+                                    w[((size_t)co * L.cin + c1) * taps + ((size_t)kz * k + (dy + 1)) * k + (dx + 1)];
+                            }
+                }
+        }
+        if (!sp.low_with_skip) sub_w.insert(sub_w.end(), eff.begin(), eff.end());          // [parity][cout][c1][taps1]
+        if (upload_split_weights(ctx, m, sp.low_with_skip ? *sp.ks_low_plain : *sp.ks_low, eff.data(), L.cout, c1e,
+                                 &sp.n_cog_low, &sp.n_chunks_low, nullptr, nullptr, k1z_n)) return 1;
         sp.w_phase_bytes = g_pack_tmp.size() * sizeof(uint16_t);
         all_w.insert(all_w.end(), g_pack_tmp.begin(), g_pack_tmp.end());
         all_s.insert(all_s.end(), g_inv_tmp.begin(), g_inv_tmp.end());
@@ -952,7 +983,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         float* X = (float*)pool_alloc(ctx, (size_t)8 * s1.H * s1.W * sizeof(float));
         if (!X) return fail(ctx, "out of device memory");
         prof_begin(ctx, 2, 0);
-        hipError_t e = launch_s2d_split(s2.p, X, s1.H, s1.W, s2.W, ctx->d_flag, ctx->stream);
+        hipError_t e = launch_s2d_split(s2.p, X, 1, s1.H, s1.W, s2.H, s2.W, 2, ctx->d_flag, ctx->stream);
         prof_end(ctx);
         if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "s2d failed: %s", hipGetErrorString(e)); }
         SplitArgs a;
@@ -983,7 +1014,16 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         return rc;
     }
     // ---- skip-source part over the full grid: bias, no activation
-    if (sp.ki_skip_stem) {
+    float* Xs2d = nullptr;
+    if (sp.low_with_skip) {
+        if (s2.pitch != s2.W || s2.ps != (long long)s2.H * s2.W) return fail(ctx, "2xf16 decoder needs a dense skip source");
+        Xs2d = (float*)pool_alloc(ctx, (size_t)8 * s1.D * s1.H * s1.W * sizeof(float));
+        if (!Xs2d) return fail(ctx, "out of device memory");
+        prof_begin(ctx, 2, 0);
+        hipError_t e = launch_s2d_split(s2.p, Xs2d, s1.D, s1.H, s1.W, s2.H, s2.W, L.dims, ctx->d_flag, ctx->stream);
+        prof_end(ctx);
+        if (e != hipSuccess) { pool_release(ctx, Xs2d); return fail(ctx, "s2d failed: %s", hipGetErrorString(e)); }
+    } else if (sp.ki_skip_stem) {
         ConvArgs a;
         memset(&a, 0, sizeof a);
         a.in = s2.p;
@@ -1049,6 +1089,12 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.flag = ctx->d_flag;
         a.slope = L.slope;
         a.cells_in = a.cells_in1 = (int)split_cells(s1.C);
+        if (sp.low_with_skip) {                        // + the space-to-depth cell of the skip source; plain epilogue
+            a.in2 = reinterpret_cast<const uint4*>(Xs2d);
+            a.cells_in = a.cells_in1 + 1;
+            a.res = nullptr;
+            a.bias = rt.d_bias;
+        }
         a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
         a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
         a.Hout = s1.H; a.Wout = s1.W;                  // the lattice of one parity
@@ -1060,7 +1106,10 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.n_chunks = sp.n_chunks_low;
         a.cog_inner = 1;
         const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W * (1 << L.dims);
-        if (launch_split(ctx, sp.ks_sub ? *sp.ks_sub : *sp.ks_low, a, sp.ks_sub ? sp.n_cog_sub : sp.n_cog_low, fl)) return 1;
+        const SplitKernelInfo& kk = sp.ks_sub ? *sp.ks_sub : (sp.low_with_skip ? *sp.ks_low_plain : *sp.ks_low);
+        const int rc = launch_split(ctx, kk, a, sp.ks_sub ? sp.n_cog_sub : sp.n_cog_low, fl);
+        if (Xs2d) pool_release(ctx, Xs2d);
+        if (rc) return 1;
     }
     return 0;
 }
