@@ -19,9 +19,15 @@
 //   into steps of 4 slots (SplitCfg::slot): with CC even the slot pairs (kb 0,1) and (kb 2,3) are the two
 //   cells of one tap; with CC = 1 they are vertically adjacent taps.  Either way the two 16-byte reads of a
 //   ds_read_b128 lane group are a multiple of 256 bytes apart: conflict-free (MI355X_MICROARCH.md, LDS).
-// Workgroup = 512 threads = 8 waves (two per SIMD), one per CU; tile = MT output channels x (TH x TW)
-//   pixels, rows strided by the dilation as in conv_mfma.h.  Wave tile = MT x (TH/8 rows x TW) pixels:
-//   per step 2*MW + 2*NW ds_read_b128 feed 3*MW*NW MFMAs.
+// Workgroup = 512 threads = 8 waves (two per SIMD), one per CU -- or, where the LDS tile fits 80 KB (dilation 1,
+//   Cout <= 96), 256 threads = 4 waves, two workgroups per CU so that one's prologue / epilogue / barrier waits
+//   hide under the other's MFMAs; tile = MT output channels x (TH x TW) pixels, rows strided by the dilation as
+//   in conv_mfma.h.  Wave tile = MT x (TH/WAVES rows x TW) pixels: per step 2*MW + 2*NW ds_read_b128 feed
+//   3*MW*NW MFMAs.
+// The same kernel carries the U-Nets (denoising/models.py:74-244, 452-564): a second source with the nearest
+//   upsample + concat folded into the loader, per-axis pads and a strided output lattice (the per-parity forms
+//   of the decoder convs, SplitArgs::nphase / subpix_cout), K x 1 "column" tap shapes (stems, 1-output-channel
+//   convs), an fp32-storing and a max-pooling epilogue.
 // Pipeline: one stage = one step.  Weights of step s+1 and, spread over the steps of a chunk, the input
 //   tile of the next chunk arrive by LDS-DMA (global_load_lds_dwordx4: one cell per lane) into the other
 //   LDS buffers while step s computes; one barrier per step.
