@@ -63,6 +63,9 @@ int bench(const char* name, int cin, int cout, int H) {
 #define RUN(ABL, label) { float ms = run<C, EPI, ABL>(a, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", label, ms, tf / (ms * 1e-3)); }
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
+    { SplitArgs b = a; b.issuer_half = 1; float ms = run<C, EPI, 0>(b, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", "upper half of the waves issues all DMA", ms, tf / (ms * 1e-3)); }
+    { SplitArgs b = a; b.issuer_half = 1; float ms = run<C, EPI, 0>(b, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", "upper half issues all DMA (again)", ms, tf / (ms * 1e-3)); }
+    RUN(0, "baseline (third)");
     RUN(1, "no epilogue loads/stores");
     RUN(32, "no residual loads");
     RUN(64, "no stores");
@@ -81,6 +84,8 @@ int bench(const char* name, int cin, int cout, int H) {
 int main() {
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_RES>("K3 D4 MT128 RES (ResNet8 block2 conv1)", 64, 128, 2048);
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_PLAIN>("K3 D4 MT128 PLAIN", 128, 128, 2048);
-    bench<SplitCfg<3, 1, 96, 8, 32, 2, 4>, EPI_PLAIN>("K3 D1 MT96 PLAIN 4-wave (U-Net dec2.2)", 96, 96, 1012);
+    bench<SplitCfg<5, 4, 128, 16, 32, 2>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
+    bench<SplitCfg<3, 2, 64, 16, 32, 2>, EPI_PLAIN>("K3 D2 MT64 PLAIN (ResNet8 conv0)", 64, 64, 2048);
+    bench<SplitCfg<3, 8, 128, 16, 32, 2>, EPI_RES>("K3 D8 MT128 RES", 128, 128, 2048);
     return 0;
 }

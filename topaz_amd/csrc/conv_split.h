@@ -82,6 +82,7 @@ struct SplitArgs {
     // channels of one conv (sub-pixel convolution), virtual channel v = parity * Cout + co stored at pixel
     // (2*oy + py, 2*ox + px), channel co.  subpix_cout = the real Cout (0 = off); wscale has 4 * Cout entries.
     int subpix_cout;
+    int issuer_half;          // 1: only the upper half of the waves issues the per-step DMA (each for two waves' shares)
     int n_chunks;             // chunks of CC (virtual) cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const void* zsrc = uniform_ptr(a.zeros);
 
     // round r of the input tile of chunk ch -> input buffer buf (both planes)
-    auto issue_input = [&](int ch, int buf, int r) {
+    auto issue_input = [&](int ch, int buf, int r, int tid, int wave) {
         const int g = r * C::THREADS + tid;
         if (g < C::NPC) {
             const bool second = ch >= chunks1;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             }
         }
     };
-    auto issue_weights = [&](const unsigned char* wcog, int st, int buf) {
+    auto issue_weights = [&](const unsigned char* wcog, int st, int buf, int tid, int wave) {
         const void* base = uniform_ptr(wcog + (size_t)st * C::W_STEP_BYTES);
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STEP_BYTES + wave * 1024));
 #pragma unroll
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         __syncthreads();                       // slot table written / previous co-group done with the buffers
         compute_offsets(chunks1 == 0);
 #pragma unroll 1
-        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r);
-        issue_weights(wcog, 0, 0);
+        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r, tid, wave);
+        issue_weights(wcog, 0, 0, tid, wave);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -321,11 +322,18 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const int j = s - ch * C::NSTEP;
             // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
             if constexpr (!(ABL & 2)) {
-                if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1);
-                if (ch + 1 < a.n_chunks) {
-                    if (j == 0 && ch + 1 == chunks1) compute_offsets(true);      // switching to the second source
+                // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
+                // start their MFMAs at once and keep the matrix core busy meanwhile)
+                const bool iss = a.issuer_half && C::WAVES == 8 && !a.in2;
+                const int reps = iss ? (wave >= 4 ? 2 : 0) : 1;
+                for (int rep = 0; rep < reps; ++rep) {
+                    const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
+                    if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1, vt, vw);
+                    if (ch + 1 < a.n_chunks) {
+                        if (j == 0 && ch + 1 == chunks1) compute_offsets(true);      // switching to the second source
 #pragma unroll 1
-                    for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r);
+                        for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r, vt, vw);
+                    }
                 }
             }
             // ---- the step's MFMAs

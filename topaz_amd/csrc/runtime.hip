@@ -952,6 +952,7 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     a.tiles_x = (a.Wout + ks.TW - 1) / ks.TW;
     a.tiles_y = (a.Hout + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
     a.xcd_swizzle = 1;
+    a.issuer_half = ks.WAVES == 8 && ks.MT >= 96;   // -3 .. -4 % on the 128-channel tiles, nothing at 64 (tools/split_ablate.hip)
     if (a.KZ < 1) { a.KZ = 1; a.pad_z = 0; a.Din = a.Dout = a.Dfull = a.Dres = 1; a.ooz = 0; }     // 2-D launch
     if (a.Dres < 1) a.Dres = 1;
     a.ncz = n_cog / a.cog_inner;
