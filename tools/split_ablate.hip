@@ -34,7 +34,8 @@ int bench(const char* name, int cin, int cout, int H) {
     const size_t cells_in = (cin + 7) / 8, cells_out = (cout + 7) / 8;
     const size_t n_in = cells_in * 8 * H * H, n_out = cells_out * 8 * (size_t)Ho * Ho;
     const int n_cog = (cout + C::MT - 1) / C::MT, n_chunks = (int)((cells_in + C::CC - 1) / C::CC);
-    const size_t n_w = (size_t)n_cog * n_chunks * C::NSTEP * C::W_STEP_BYTES / 4;
+    const int n_st = C::CONT ? C::cont_stages(n_chunks) : n_chunks * C::NSTEP;
+    const size_t n_w = (size_t)n_cog * n_st * C::W_STEP_BYTES / 4;
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;
     CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
@@ -59,7 +60,7 @@ int bench(const char* name, int cin, int cout, int H) {
     dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
-           n_chunks * C::NSTEP * a.cog_inner);
+           n_st * a.cog_inner);
 #define RUN(ABL, label) { float ms = run<C, EPI, ABL>(a, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", label, ms, tf / (ms * 1e-3)); }
     RUN(0, "baseline");
     RUN(0, "baseline (again)");

@@ -119,6 +119,14 @@ struct SplitCfg {
     static constexpr int PV = KX * (K / 2);                             // vertical tap pairs (CC == 1)
     static constexpr int PAIRS1 = PV + ((K % 2) ? (ROWPAIR ? KX - 1 : KX) : 0);
     static constexpr int NSTEP = (CC == 1) ? (PAIRS1 + 1) / 2 : (K * KX * CC + 3) / 4;
+    // CC even: the slots of consecutive chunks form ONE stream, q = G % Q, chunk = G / Q for the global slot
+    // G = 4 * stage + kb -- a step may take its first two slots from the end of chunk c and the last two from the
+    // start of chunk c + 1 (both tiles are resident: double buffer), so only the very last step of a tile is padded:
+    // 3x3 x 2 cells = 18 slots per chunk cost 4.5 steps instead of 5, 5x5 x 2 = 50 slots 12.5 instead of 13.
+    static constexpr bool CONT = (CC % 2 == 0);
+    static constexpr int Q = K * KX * CC;                               // slots per chunk (CONT)
+    __host__ __device__ static constexpr int cont_stages(int n_chunks) { return (Q * n_chunks + 3) / 4; }
+    __host__ __device__ static constexpr SplitSlot cont_slot(int q) { return SplitSlot{(q / CC) / KX, (q / CC) % KX, q % CC}; }
     __host__ __device__ static constexpr SplitSlot slot(int step, int kb) {
         if (CC != 1) {
             const int q = step * 4 + kb, t = q / CC;
@@ -145,7 +153,8 @@ struct SplitCfg {
     static constexpr int OFF_W = 2 * IN_BUF;
     static constexpr int OFF_TAB = OFF_W + 2 * W_STEP_BYTES;
     static constexpr int OFF_SLOT = OFF_TAB + NPC * 4;
-    static constexpr int LDS_BYTES = OFF_SLOT + NSTEP * 16;
+    static constexpr int N_SLOT_TAB = CONT ? Q : NSTEP * 4;
+    static constexpr int LDS_BYTES = OFF_SLOT + (N_SLOT_TAB + 3) / 4 * 16;
     static_assert(TH % WAVES == 0 && TW % 16 == 0 && MT % 16 == 0, "tile shape");
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
     static_assert(LDS_BYTES <= 160 * 1024 / WGS_PER_CU, "LDS per workgroup");
@@ -200,7 +209,14 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 
     constexpr unsigned OOB = 0xffffffffu;
     // ---- tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell of a source
-    if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
+    if constexpr (C::CONT) {
+        if (tid < C::Q) {
+            const SplitSlot sl = C::cont_slot(tid);
+            lds_slot[tid] = (unsigned)((sl.c * C::CELL_STRIDE + sl.ky * C::ITW + sl.kx * D) * 16);
+        }
+    } else {
+        if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
+    }
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
     auto compute_offsets = [&](bool second) {
         const int Hs = second ? a.Hin : a.H1, Ws = second ? a.Win : a.W1;
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
     bool big = false;
 
-    const int n_stages = a.n_chunks * C::NSTEP;
+    const int n_stages = C::CONT ? C::cont_stages(a.n_chunks) : a.n_chunks * C::NSTEP;
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
@@ -318,8 +334,23 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 
 #pragma unroll 1
         for (int s = 0; s < n_stages; ++s) {
-            const int ch = s / C::NSTEP;
-            const int j = s - ch * C::NSTEP;
+            // chunk of the step's first slot; pf = chunk whose tile is being prefetched, r0 / rstride = its DMA rounds
+            int ch, pf, r0, rstride;
+            if constexpr (C::CONT) {
+                ch = (4 * s) / C::Q;
+                pf = ch + 1;
+                // buffer pf & 1 is free once the last slot of chunk pf - 2 is done and must be full before the first
+                // slot of chunk pf: stages [ws, we]; the step that straddles two chunks issues nothing
+                const int ws = pf >= 2 ? (C::Q * (pf - 1) - 1) / 4 + 1 : 0;
+                const int we = (C::Q * pf) / 4 - 1;
+                r0 = (s >= ws && s <= we) ? s - ws : C::NR;
+                rstride = we - ws + 1;
+            } else {
+                ch = s / C::NSTEP;
+                pf = ch + 1;
+                r0 = s - ch * C::NSTEP;
+                rstride = C::NSTEP;
+            }
             // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
             if constexpr (!(ABL & 2)) {
                 // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
@@ -329,15 +360,22 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 for (int rep = 0; rep < reps; ++rep) {
                     const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
                     if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1, vt, vw);
-                    if (ch + 1 < a.n_chunks) {
-                        if (j == 0 && ch + 1 == chunks1) compute_offsets(true);      // switching to the second source
+                    if (pf < a.n_chunks && r0 < C::NR) {
+                        if (r0 == 0 && pf == chunks1) compute_offsets(true);         // switching to the second source
 #pragma unroll 1
-                        for (int r = j; r < C::NR; r += C::NSTEP) issue_input(ch + 1, (ch + 1) & 1, r, vt, vw);
+                        for (int r = r0; r < C::NR; r += rstride) issue_input(pf, pf & 1, r, vt, vw);
                     }
                 }
             }
             // ---- the step's MFMAs
-            const unsigned char* bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[j * 4 + l4];
+            const unsigned char* bl;
+            if constexpr (C::CONT) {
+                int G = 4 * s + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
+                if (cg2 >= a.n_chunks) { cg2 = a.n_chunks - 1; q = 0; }            // padding slots of the last step (zero weights)
+                bl = lds + (cg2 & 1) * C::IN_BUF + b_lane + lds_slot[q];
+            } else {
+                bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[(s - ch * C::NSTEP) * 4 + l4];
+            }
             const unsigned char* al = lds + a_lane + (s & 1) * C::W_STEP_BYTES;
             f16x8 bh[NW], bo[NW];
 #pragma unroll

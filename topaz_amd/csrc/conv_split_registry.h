@@ -9,7 +9,10 @@ namespace tpz {
 struct SplitKernelInfo {
     int K, D, MT, epi;
     int KX, TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes;
+    int cont, Q;                               // continuous slot stream (SplitCfg::CONT): Q slots per chunk
     SplitSlot (*slot)(int step, int kb);
+    SplitSlot (*cont_slot)(int q);
+    int stages(int n_chunks) const { return cont ? (Q * n_chunks + 3) / 4 : n_chunks * NSTEP; }
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
     char name[160];
 };
@@ -32,6 +35,8 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
 
 template <class C>
 SplitSlot split_slot_of(int step, int kb) { return C::slot(step, kb); }
+template <class C>
+SplitSlot split_cont_slot_of(int q) { return C::cont_slot(q); }
 
 template <class C, int EPI>
 struct SplitRegistrar {
@@ -41,6 +46,8 @@ struct SplitRegistrar {
         i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.WAVES = C::WAVES; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
         i.lds_bytes = C::LDS_BYTES;
         i.slot = &split_slot_of<C>;
+        i.cont = C::CONT ? 1 : 0; i.Q = C::Q;
+        i.cont_slot = &split_cont_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
         snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,
                  i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.epi);

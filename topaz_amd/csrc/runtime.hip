@@ -486,34 +486,45 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
         wscale_inv[co] = std::ldexp(1.f, -e);
     }
     const size_t step_halfs = (size_t)ki.W_STEP_BYTES / 2;
-    out.assign((size_t)n_cog * n_chunks * ki.NSTEP * step_halfs, 0);
+    const int n_stages = ki.stages(n_chunks);
+    out.assign((size_t)n_cog * n_stages * step_halfs, 0);
     for (int cog = 0; cog < n_cog; ++cog)
-        for (int ch = 0; ch < n_chunks; ++ch)
-            for (int step = 0; step < ki.NSTEP; ++step) {
-                uint16_t* blk = out.data() + (((size_t)cog * n_chunks + ch) * ki.NSTEP + step) * step_halfs;
-                for (int kb = 0; kb < 4; ++kb) {
-                    const SplitSlot sl = ki.slot(step, kb);
+        for (int st = 0; st < n_stages; ++st) {
+            uint16_t* blk = out.data() + ((size_t)cog * n_stages + st) * step_halfs;
+            for (int kb = 0; kb < 4; ++kb) {
+                // (chunk, tap, cell) of lane group kb in this step
+                int ch;
+                SplitSlot sl;
+                if (ki.cont) {
+                    const int G = 4 * st + kb;
+                    ch = G / ki.Q;
+                    if (ch >= n_chunks) continue;                   // padding slots of the last step
+                    sl = ki.cont_slot(G % ki.Q);
+                } else {
+                    ch = st / ki.NSTEP;
+                    sl = ki.slot(st % ki.NSTEP, kb);
                     if (sl.ky < 0) continue;
-                    for (int m = 0; m < MW; ++m)
-                        for (int i = 0; i < 16; ++i) {
-                            const int co = cog * ki.MT + m * 16 + i;
-                            if (co >= cout) continue;
-                            for (int j = 0; j < 8; ++j) {
-                                const int ci = (ch * ki.CC + sl.c) * 8 + j;
-                                if (ci >= cin) continue;
-                                const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * KX + sl.kx] * scale[co];
-                                const _Float16 hi = (_Float16)v;
-                                const _Float16 lo = (_Float16)(v - (float)hi);
-                                uint16_t hb, lb;
-                                memcpy(&hb, &hi, 2);
-                                memcpy(&lb, &lo, 2);
-                                const size_t lane = (size_t)kb * 16 + i;
-                                blk[((size_t)(0 * MW + m) * 64 + lane) * 8 + j] = hb;
-                                blk[((size_t)(1 * MW + m) * 64 + lane) * 8 + j] = lb;
-                            }
-                        }
                 }
+                for (int m = 0; m < MW; ++m)
+                    for (int i = 0; i < 16; ++i) {
+                        const int co = cog * ki.MT + m * 16 + i;
+                        if (co >= cout) continue;
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = (ch * ki.CC + sl.c) * 8 + j;
+                            if (ci >= cin) continue;
+                            const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * KX + sl.kx] * scale[co];
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            uint16_t hb, lb;
+                            memcpy(&hb, &hi, 2);
+                            memcpy(&lb, &lo, 2);
+                            const size_t lane = (size_t)kb * 16 + i;
+                            blk[((size_t)(0 * MW + m) * 64 + lane) * 8 + j] = hb;
+                            blk[((size_t)(1 * MW + m) * 64 + lane) * 8 + j] = lb;
+                        }
+                    }
             }
+        }
 }
 
 static const SplitKernelInfo* pick_split(int k, int dil, int cout, int epi, int kx = 0) {
@@ -816,7 +827,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         }
         if (readers != 1 || pool != i + 1) continue;
         const SplitKernelInfo* pk = find_split(base->K, base->D, base->MT, EPI_POOL, base->KX);
-        if (pk && pk->CC == base->CC && pk->NSTEP == base->NSTEP && pk->W_STEP_BYTES == base->W_STEP_BYTES) rt.ks_pool = pk;
+        if (pk && pk->CC == base->CC && pk->NSTEP == base->NSTEP && pk->cont == base->cont && pk->W_STEP_BYTES == base->W_STEP_BYTES) rt.ks_pool = pk;
     }
     m->split_ok = any_split;
     return 0;
