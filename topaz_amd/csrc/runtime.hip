@@ -52,6 +52,8 @@ static std::string g_last_error;
 static const bool g_no_phase = getenv("TPZ_NO_PHASE") != nullptr;
 // TPZ_EXACT_FP32=1 keeps every network on the fp32 MFMA kernels (the 2xf16 path of conv_split.h is never taken)
 static const bool g_exact_fp32 = getenv("TPZ_EXACT_FP32") != nullptr;
+// TPZ_NO_ISSUER=1: every wave issues its own share of the per-step LDS-DMA (A/B switch for tuning, see launch_split)
+static const bool g_no_issuer = getenv("TPZ_NO_ISSUER") != nullptr;
 
 struct ProfRec {
     int cls;
@@ -963,7 +965,7 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     a.tiles_x = (a.Wout + ks.TW - 1) / ks.TW;
     a.tiles_y = (a.Hout + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
     a.xcd_swizzle = 1;
-    a.issuer_half = ks.WAVES == 8 && ks.MT >= 96;   // -3 .. -4 % on the 128-channel tiles, nothing at 64 (tools/split_ablate.hip)
+    a.issuer_half = ks.WAVES == 8 && ks.MT >= 96 && !g_no_issuer;   // -3 .. -4 % on the 128-channel tiles, nothing at 64 (tools/split_ablate.hip)
     if (a.KZ < 1) { a.KZ = 1; a.pad_z = 0; a.Din = a.Dout = a.Dfull = a.Dres = 1; a.ooz = 0; }     // 2-D launch
     if (a.Dres < 1) a.Dres = 1;
     a.ncz = n_cog / a.cog_inner;
