@@ -234,3 +234,30 @@ def test_unet_odd_widths_mixed_paths(gpu_ctx, nf, bw, tw):
     ref = oden.denoise('unet', sd, x)
     y = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
     assert _err(y, ref) <= 1e-4
+
+
+def test_conv_split_random_shapes_vs_fp32_kernels(gpu_ctx):
+    """Randomised sweep: the 2xf16 kernel against the fp32 MFMA kernel of the same layer (both through the C-ABI)
+    over kernel sizes / dilations / paddings / odd channel counts and image sizes around the tile boundaries."""
+    from topaz_amd import runtime as rt
+    rs = np.random.RandomState(77)
+    combos = [(3, 1, 96), (3, 1, 48), (3, 1, 64), (3, 2, 64), (3, 4, 64), (3, 4, 128), (3, 8, 128), (3, 2, 128),
+              (5, 4, 128), (1, 1, 128), (1, 1, 64), (3, 1, 32), (3, 2, 32), (3, 4, 32), (5, 2, 32), (5, 4, 32), (5, 8, 32),
+              (2, 1, 96), (2, 1, 64), (5, 1, 32)]
+    for case in range(40):
+        k, dil, cout_max = combos[rs.randint(len(combos))]
+        cout = int(cout_max if rs.rand() < 0.5 else rs.randint(max(cout_max // 2 + 1, 1), cout_max + 1))
+        cin = int(rs.choice([8, 16, 24, 40, 48, 64, 72, 96, 128]))
+        pad = int(rs.choice([0, k // 2, 1])) if k > 1 else 0
+        span = dil * (k - 1)
+        H = span + 1 - 2 * pad + int(rs.randint(1, 70))
+        W = span + 1 - 2 * pad + int(rs.randint(1, 90))
+        H, W = max(H, 1), max(W, 1)
+        x = torch.from_numpy(rs.randn(cin, H, W).astype(np.float32))
+        w = (rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = rs.randn(cout).astype(np.float32)
+        slope = float(rs.choice([0.0, 0.1, 1.0]))
+        y32 = rt.conv(x, w, b, dil=dil, pad=pad, slope=slope)
+        ys, ovf = rt.conv_split(x, w, b, dil=dil, pad=pad, slope=slope)
+        assert not ovf
+        assert _err(ys, y32) <= 1e-4, (case, k, dil, cin, cout, pad, H, W, _err(ys, y32))
