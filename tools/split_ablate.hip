@@ -39,7 +39,7 @@ int bench(const char* name, int cin, int cout, int H) {
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;
     CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
-    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, cout * 4)); CHK(hipMalloc(&flag, 16));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 16));
     CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 16));
     // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
     std::vector<uint16_t> h(1 << 21);

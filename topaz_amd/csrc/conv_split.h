@@ -49,7 +49,8 @@ struct SplitArgs {
     const uint4* in2;         // optional second source [2][cells_in - cells_in1][Hin][Win]: channels after those of
                               // `in`, which is then nearest-upsampled to Hin x Win (fused upsample + concat)
     const uint4* wpk;         // packed weights (runtime.hip pack_weights_split)
-    const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling
+    const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling.  This and the other per-channel vectors
+                              // are zero-padded to whole tiles (runtime.hip chan_pad): fetched as unclamped float4
     const float* bias;        // [Cout] or nullptr
     uint4* out;               // split tensor [2][cells_out][Hfull][Wfull] (nullptr: fused head / fp32 output)
     float* out_f32;           // EPI_PLAIN_F32: fp32 planes [Cout][Hfull][Wfull] instead
@@ -76,7 +77,7 @@ struct SplitArgs {
     // all output parities of a decoder conv in one launch (runtime.hip prepare_split_phases): phase p = (pz, py, px)
     // bits uses weights wpk + p * w_phase_bytes, scales wscale + p * Cout, pad (phase_k/2 - parity + 1)/2 and
     // lattice offset = parity on each axis (pad_* / oo* of the struct are then ignored)
-    int nphase, phase_k;
+    int nphase, phase_k, ws_phase_stride;
     size_t w_phase_bytes;
     // or, when every parity reads the same window (5x5 -> 3x3 taps, pad 1): the parities as 4 * Cout VIRTUAL output
     // channels of one conv (sub-pixel convolution), virtual channel v = parity * Cout + co stored at pixel
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const int cog = cogz * a.cog_inner + cg;
         const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)phase * a.w_phase_bytes +
                                     (size_t)cog * w_cog_bytes;
-        const float* wscale = a.wscale + (size_t)phase * a.Cout;
+        const float* wscale = a.wscale + (size_t)phase * a.ws_phase_stride;
         f32x4 acc[MW][NW];
 #pragma unroll
         for (int m = 0; m < MW; ++m)
@@ -443,24 +444,33 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // 4 consecutive (virtual) channels: half a cell
-            int co0 = cov0, sy = 0, sx = 0, n_virt = a.Cout;
+            int co0 = cov0, sy = 0, sx = 0;
             if (a.subpix_cout > 0) {                               // Cout % 16 == 0: one parity per fragment
                 const int par = cov0 / a.subpix_cout;
                 co0 = cov0 - par * a.subpix_cout;
                 sx = par & 1; sy = (par >> 1) & 1;
-                n_virt = 4 * a.subpix_cout;
                 if (par > 3) co0 = a.Cout;                         // padding fragments of the last co-group
             }
             const int cell = co0 >> 3, half = (co0 >> 2) & 1;
             const int cellc = cell < a.cells_out ? cell : a.cells_out - 1;
+            // per-channel constants: one float4 each (arrays zero-padded to whole tiles: no clamps, padded channels -> 0)
             float sc[4], bi[4], psc[4], psh[4], hw[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cc = co0 + r < a.Cout ? co0 + r : a.Cout - 1;
-                sc[r] = wscale[cov0 + r < n_virt ? cov0 + r : n_virt - 1];
-                bi[r] = has_bias ? a.bias[cc] : 0.f;
-                if constexpr (EPI == EPI_RES_POST) { psc[r] = a.post_scale[cc]; psh[r] = a.post_shift[cc]; }
-                if constexpr (EPI == EPI_HEAD) hw[r] = a.head_w[cc];
+            {
+                const float4 s4 = *reinterpret_cast<const float4*>(wscale + cov0);
+                sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has_bias) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
+                bi[0] = b4.x; bi[1] = b4.y; bi[2] = b4.z; bi[3] = b4.w;
+                if constexpr (EPI == EPI_RES_POST) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(a.post_scale + co0);
+                    const float4 q4 = *reinterpret_cast<const float4*>(a.post_shift + co0);
+                    psc[0] = p4.x; psc[1] = p4.y; psc[2] = p4.z; psc[3] = p4.w;
+                    psh[0] = q4.x; psh[1] = q4.y; psh[2] = q4.z; psh[3] = q4.w;
+                }
+                if constexpr (EPI == EPI_HEAD) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(a.head_w + co0);
+                    hw[0] = h4.x; hw[1] = h4.y; hw[2] = h4.z; hw[3] = h4.w;
+                }
             }
             uint2 rh[NW], rl[NW];
             if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) {

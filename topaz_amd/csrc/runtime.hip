@@ -298,6 +298,15 @@ static int upload(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** 
     return 0;
 }
 
+// per-channel vectors (bias, BN affine, head weights, weight scales) are zero-padded to whole 128-channel tiles plus one,
+// so the epilogues fetch them as unclamped float4 loads; zero scale / bias make the padded channels come out as 0
+static size_t chan_pad(size_t n) { return (n + 127) / 128 * 128 + 128; }
+static int upload_chan(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** out) {
+    std::vector<float> padded(chan_pad(n), 0.f);
+    memcpy(padded.data(), h, n * sizeof(float));
+    return upload(ctx, m, padded.data(), padded.size(), out);
+}
+
 static const int MT_CHOICES[] = {16, 32, 48, 64, 96, 128};
 
 // choose the MFMA instantiation for a conv layer; returns nullptr when the direct kernel must be used
@@ -457,14 +466,14 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
     if (L.b_off >= 0) {
         if ((size_t)L.b_off + L.cout > n_floats) return fail(ctx, "conv: bias offset out of range");
         rt.bias0 = blob[L.b_off];
-        if (upload(ctx, m, blob + L.b_off, L.cout, &rt.d_bias)) return 1;
+        if (upload_chan(ctx, m, blob + L.b_off, L.cout, &rt.d_bias)) return 1;
     }
     if (L.post_scale_off >= 0) {
-        if (upload(ctx, m, blob + L.post_scale_off, L.cout, &rt.d_post_scale)) return 1;
-        if (upload(ctx, m, blob + L.post_shift_off, L.cout, &rt.d_post_shift)) return 1;
+        if (upload_chan(ctx, m, blob + L.post_scale_off, L.cout, &rt.d_post_scale)) return 1;
+        if (upload_chan(ctx, m, blob + L.post_shift_off, L.cout, &rt.d_post_shift)) return 1;
     }
     if (L.head) {
-        if (upload(ctx, m, blob + L.head_w_off, L.cout, &rt.d_head_w)) return 1;
+        if (upload_chan(ctx, m, blob + L.head_w_off, L.cout, &rt.d_head_w)) return 1;
         rt.head_b = blob[L.head_b_off];
     }
     return 0;
@@ -577,7 +586,7 @@ static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInf
     float* d = nullptr;
     if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
     *d_w = d;
-    return upload(ctx, m, inv.data(), inv.size(), d_ws);
+    return upload_chan(ctx, m, inv.data(), inv.size(), d_ws);
 }
 
 // 2xf16 twin of prepare_phases for a 2-D decoder layer conv(cat(upsample2x(a), b)); needs rt.phase (fp32)
@@ -651,6 +660,7 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
                                  &sp.n_cog_low, &sp.n_chunks_low, nullptr, nullptr, k1z_n)) return 1;
         sp.w_phase_bytes = g_pack_tmp.size() * sizeof(uint16_t);
         all_w.insert(all_w.end(), g_pack_tmp.begin(), g_pack_tmp.end());
+        g_inv_tmp.resize(chan_pad(L.cout), 0.f);                      // stride chan_pad(cout) per parity
         all_s.insert(all_s.end(), g_inv_tmp.begin(), g_inv_tmp.end());
     }
     // 5x5 (2-D): both parities of an axis read the same 3-tap window, so the four parity kernels share their B
@@ -1096,6 +1106,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
             a.nphase = 1 << L.dims;
             a.phase_k = L.k;
             a.w_phase_bytes = sp.w_phase_bytes;
+            a.ws_phase_stride = (int)chan_pad(L.cout);
         }
         a.out = reinterpret_cast<uint4*>(dst.p);
         a.res = reinterpret_cast<const uint4*>(dst.p);
@@ -1622,11 +1633,11 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
     float* d = nullptr;
     int rc = upload(ctx, &tmp, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d);
     rt.d_wsplit = d;
-    if (!rc) rc = upload(ctx, &tmp, inv.data(), inv.size(), &rt.d_wscale);
-    if (!rc && h_b) rc = upload(ctx, &tmp, h_b, cout, &rt.d_bias);
-    if (!rc && h_post_scale) rc = upload(ctx, &tmp, h_post_scale, cout, &rt.d_post_scale);
-    if (!rc && h_post_shift) rc = upload(ctx, &tmp, h_post_shift, cout, &rt.d_post_shift);
-    if (!rc && h_head_w) { rc = upload(ctx, &tmp, h_head_w, cout, &rt.d_head_w); rt.head_b = head_b; }
+    if (!rc) rc = upload_chan(ctx, &tmp, inv.data(), inv.size(), &rt.d_wscale);
+    if (!rc && h_b) rc = upload_chan(ctx, &tmp, h_b, cout, &rt.d_bias);
+    if (!rc && h_post_scale) rc = upload_chan(ctx, &tmp, h_post_scale, cout, &rt.d_post_scale);
+    if (!rc && h_post_shift) rc = upload_chan(ctx, &tmp, h_post_shift, cout, &rt.d_post_shift);
+    if (!rc && h_head_w) { rc = upload_chan(ctx, &tmp, h_head_w, cout, &rt.d_head_w); rt.head_b = head_b; }
     Slot s1, sres, dst;
     float *x_s = nullptr, *r_s = nullptr, *y_s = nullptr;
     const int Hr = Ho + 2 * res_crop, Wr = Wo + 2 * res_crop;
