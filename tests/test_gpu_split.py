@@ -261,3 +261,19 @@ def test_conv_split_random_shapes_vs_fp32_kernels(gpu_ctx):
         ys, ovf = rt.conv_split(x, w, b, dil=dil, pad=pad, slope=slope)
         assert not ovf
         assert _err(ys, y32) <= 1e-4, (case, k, dil, cin, cout, pad, H, W, _err(ys, y32))
+
+
+def test_split_path_is_bitwise_reproducible(gpu_ctx):
+    """no atomics in any accumulation: repeated runs of the same image give bit-identical logits / pixels"""
+    from tools import synth_weights as sw
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    m, _ = sw.hip_resnet('resnet8', 64, 7)
+    x = torch.from_numpy(np.random.RandomState(5).randn(700, 650).astype(np.float32)).cuda()
+    y0 = m(x[None, None])[0, 0].clone()
+    for _ in range(3):
+        assert torch.equal(y0, m(x[None, None])[0, 0])
+    dn = Denoise(DenoiseNet('unet', sw.unet_sd(11)))
+    z0 = dn.denoise_device(x, 256, 64).clone()
+    for _ in range(2):
+        assert torch.equal(z0, dn.denoise_device(x, 256, 64))
