@@ -34,7 +34,7 @@ int bench(const char* name, int cin, int cout, int H) {
     const size_t cells_in = (cin + 7) / 8, cells_out = (cout + 7) / 8;
     const size_t n_in = cells_in * 8 * H * H, n_out = cells_out * 8 * (size_t)Ho * Ho;
     const int n_cog = (cout + C::MT - 1) / C::MT, n_chunks = (int)((cells_in + C::CC - 1) / C::CC);
-    const int n_st = C::CONT ? C::cont_stages(n_chunks) : n_chunks * C::NSTEP;
+    const int n_st = C::CONT ? C::cont_stages((int)cells_in) : n_chunks * C::NSTEP;
     const size_t n_w = (size_t)n_cog * n_st * C::W_STEP_BYTES / 4;
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;

@@ -126,7 +126,10 @@ struct SplitCfg {
     // 3x3 x 2 cells = 18 slots per chunk cost 4.5 steps instead of 5, 5x5 x 2 = 50 slots 12.5 instead of 13.
     static constexpr bool CONT = (CC % 2 == 0);
     static constexpr int Q = K * KX * CC;                               // slots per chunk (CONT)
-    __host__ __device__ static constexpr int cont_stages(int n_chunks) { return (Q * n_chunks + 3) / 4; }
+    // `cells` (virtual) cells in all: the last chunk may hold fewer than CC -- its slots enumerate its own cells only
+    static constexpr int TAPS = K * KX;
+    __host__ __device__ static constexpr int cont_slots(int cells) { return TAPS * cells; }
+    __host__ __device__ static constexpr int cont_stages(int cells) { return (TAPS * cells + 3) / 4; }
     __host__ __device__ static constexpr SplitSlot cont_slot(int q) { return SplitSlot{(q / CC) / KX, (q / CC) % KX, q % CC}; }
     __host__ __device__ static constexpr SplitSlot slot(int step, int kb) {
         if (CC != 1) {
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
     bool big = false;
 
-    const int n_stages = C::CONT ? C::cont_stages(a.n_chunks) : a.n_chunks * C::NSTEP;
+    const int vcells = a.cells_in * (vol ? a.KZ : 1);        // (virtual) cells of the K loop
+    const int n_full = vcells / C::CC, n_rem = vcells - n_full * C::CC;      // full chunks; cells of a short last chunk
+    const int n_stages = C::CONT ? C::cont_stages(vcells) : a.n_chunks * C::NSTEP;
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
@@ -372,7 +377,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const unsigned char* bl;
             if constexpr (C::CONT) {
                 int G = 4 * s + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
-                if (cg2 >= a.n_chunks) { cg2 = a.n_chunks - 1; q = 0; }            // padding slots of the last step (zero weights)
+                if (cg2 >= n_full) {
+                    // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond
+                    // it the padding slots of the last step (zero weights, any valid address)
+                    const int q2 = G - n_full * C::Q;
+                    cg2 = n_full < a.n_chunks ? n_full : a.n_chunks - 1;
+                    q = (n_rem > 0 && q2 < C::TAPS * n_rem) ? (q2 / n_rem) * C::CC + (q2 % n_rem) : 0;
+                }
                 bl = lds + (cg2 & 1) * C::IN_BUF + b_lane + lds_slot[q];
             } else {
                 bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[(s - ch * C::NSTEP) * 4 + l4];

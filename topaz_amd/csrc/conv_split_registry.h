@@ -12,7 +12,8 @@ struct SplitKernelInfo {
     int cont, Q;                               // continuous slot stream (SplitCfg::CONT): Q slots per chunk
     SplitSlot (*slot)(int step, int kb);
     SplitSlot (*cont_slot)(int q);
-    int stages(int n_chunks) const { return cont ? (Q * n_chunks + 3) / 4 : n_chunks * NSTEP; }
+    // steps of one tile's K loop over `cells` (virtual) cells
+    int stages(int cells) const { return cont ? ((Q / CC) * cells + 3) / 4 : (cells + CC - 1) / CC * NSTEP; }
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
     char name[160];
 };

@@ -497,7 +497,9 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
         wscale_inv[co] = std::ldexp(1.f, -e);
     }
     const size_t step_halfs = (size_t)ki.W_STEP_BYTES / 2;
-    const int n_stages = ki.stages(n_chunks);
+    const int cells = (int)split_cells(cin);
+    const int n_stages = ki.stages(cells);
+    const int n_full = cells / ki.CC, n_rem = cells - n_full * ki.CC, taps_n = ki.cont ? ki.Q / ki.CC : 0;
     out.assign((size_t)n_cog * n_stages * step_halfs, 0);
     for (int cog = 0; cog < n_cog; ++cog)
         for (int st = 0; st < n_stages; ++st) {
@@ -509,8 +511,15 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
                 if (ki.cont) {
                     const int G = 4 * st + kb;
                     ch = G / ki.Q;
-                    if (ch >= n_chunks) continue;                   // padding slots of the last step
-                    sl = ki.cont_slot(G % ki.Q);
+                    if (ch < n_full) {
+                        sl = ki.cont_slot(G % ki.Q);
+                    } else {
+                        // short last chunk: (tap, cell) over its own n_rem cells; then the padding slots of the last step
+                        const int q2 = G - n_full * ki.Q;
+                        if (n_rem == 0 || q2 >= taps_n * n_rem) continue;
+                        ch = n_full;
+                        sl = ki.cont_slot((q2 / n_rem) * ki.CC + (q2 % n_rem));
+                    }
                 } else {
                     ch = st / ki.NSTEP;
                     sl = ki.slot(st % ki.NSTEP, kb);
