@@ -114,3 +114,17 @@ def test_patch_geometry_helpers():
     cropped = [p[0, 0, pad:-pad, pad:-pad].numpy() for p in patches]
     assert np.array_equal(reconstruct_from_patches(cropped, X.shape, size, pad)[0, 0], X[0, 0].numpy())
     assert insize_from_outsize([dict(kernel_size=7, stride=2), dict(kernel_size=5)], 1) == 15
+
+
+def test_bench_weights_equal_test_weights():
+    """bench.py / tools take their seeded ResNet weights from tools/synth_weights.py with recorded probe statistics
+    (no oracle call); they must stay bit-identical to the oracle-calibrated weights the parity tests use."""
+    import numpy as np
+    from oracle import scoring as oscoring
+    from tools import synth_weights as sw
+    for (arch, units, seed, bn), stats in sw.KNOWN_PROBE_STATS.items():
+        a = oscoring.synthetic_resnet_sd(arch, units, seed, bn)
+        b = sw.calibrate_head(sw.resnet_sd_uncalibrated(arch, units, seed, bn), stats)
+        assert list(a) == list(b)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (arch, k)
