@@ -11,14 +11,21 @@ through the whole path on one GPU:
     NMS             radius 14, threshold -6  -> pick table
 The pretrained blobs of both default architectures are absent upstream, so
 the weights are seeded random (calibrated to realistic logit statistics) -- the arithmetic and the
-shapes are those of the named configs.  Multi-GPU (torchrun): every rank processes its own K images
-(weak scaling), then the pick tables are gathered to rank 0 over RCCL (the only collective).
+shapes are those of the named configs.  Multi-GPU: every rank processes its own K images (weak scaling),
+then the pick tables are gathered to rank 0 over RCCL (the only collective; timed separately as `gather_ms`).
+`--gpus N` under torchrun uses the ranks it is given; run as plain `python bench.py --gpus N` it starts its own N
+rank processes (topaz_amd.parallel.launch_local_ranks), one per GPU, and rank 0 prints the line.
 
 Prints ONE JSON line (see the driver contract) including
   roofline     -- the dominant kernel class (conv_mfma, fp32 matrix cores): algorithmic FLOP / HIP-event
                   time of those launches, measured live in a separate profiled step after the timed region
   cpu_baseline -- the oracle (CPU restatement of the reference, torch-CPU) timed on a bounded sample of
-                  the same workload on this host, rank 0 and N=1 only.
+                  the same workload on this host, rank 0 and N=1 only (`--cpu-full`: one whole 4096^2 micrograph).
+  exact_fp32   -- the same step with every convolution pinned to the fp32-MFMA kernels (tpz_ctx_set_exact)
+  pcie_inclusive -- the same step fed from pinned host memory through the host-pointer entry points (H2D of the
+                  micrograph, D2H of the pick table, double-buffered), N=1 only.
+`--dry-run` (CPU box, no GPU): skips the hot path and fabricates pick tables so that the launcher, the barriers and the
+gather can be exercised over gloo; its line carries "dry_run": true and is not a measurement.
 """
 from __future__ import annotations
 
@@ -66,22 +73,36 @@ def run_step(models, x_dev, args):
     return img, None
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(models, args):
-    """oracle timed on a bounded sample: a SxS crop of micrograph 0 through the same stages; scaled to
-    micrographs/s by the pixel counts the full workload processes (patched denoising touches 3.0x the
-    image)."""
+    """The oracle (torch-CPU convs, C NMS) timed on this host.  Default: a bounded sample -- an SxS crop of micrograph
+    0 through the same stages, scaled to micrographs/s by the pixel counts the full workload processes (patched
+    denoising touches 3.0x the image).  --cpu-full: micrograph 0 itself at the full size with the
+    same patching (minutes of CPU time; nothing is scaled)."""
     from oracle import denoising as oden
     from oracle import nms as onms
     from oracle import scoring as oscoring
-    S = args.cpu_sample
-    x = np.random.RandomState(1000).randn(S, S).astype(np.float32)
+    full = args.cpu_full
+    S = args.size if full else args.cpu_sample
+    x = np.random.RandomState(1000).randn(args.size, args.size).astype(np.float32)[:S, :S].copy()
     threads = torch.get_num_threads()
     per_image = 0.0
     parts = {}
     full_px = float(args.size) ** 2
     if 'denoise' in models:
         sd = models['denoise'][1]
-        t0 = time.time(); den = oden.denoise('unet', sd, x, -1); t = time.time() - t0
+        t0 = time.time()
+        den = oden.denoise('unet', sd, x, args.patch_size, args.patch_padding) if full else oden.denoise('unet', sd, x, -1)
+        t = time.time() - t0
         # pixels the full job pushes through the net with -s/-p patching
         n_px = 0
         for i in range(0, args.size, args.patch_size):
@@ -89,20 +110,115 @@ def cpu_baseline(models, args):
                 h = min(args.size, i + args.patch_size + args.patch_padding) - max(0, i - args.patch_padding)
                 w = min(args.size, j + args.patch_size + args.patch_padding) - max(0, j - args.patch_padding)
                 n_px += h * w
-        parts['denoise_s'] = t
-        per_image += t * n_px / (S * S)
+        parts['denoise_s'] = round(t, 3)
+        per_image += t if full else t * n_px / (S * S)
         x = den
     if 'score' in models:
         sd = models['score'][1]
         t0 = time.time(); logit = oscoring.score('resnet8', sd, x); t = time.time() - t0
-        parts['score_s'] = t
-        per_image += t * full_px / (S * S)
+        parts['score_s'] = round(t, 3)
+        per_image += t if full else t * full_px / (S * S)
         t0 = time.time(); onms.nms2d(logit, args.radius, args.threshold); t = time.time() - t0
-        parts['nms_s'] = t
-        per_image += t * full_px / (S * S)
+        parts['nms_s'] = round(t, 3)
+        per_image += t if full else t * full_px / (S * S)
+    sample = (f'micrograph 0 at {S}x{S} (the whole workload of one step, nothing scaled), times {parts}' if full else
+              f'{S}x{S} crop of micrograph 0 through the oracle, times {parts} scaled by processed-pixel ratio to '
+              f'{args.size}x{args.size}')
     return {'value': 1.0 / per_image, 'unit': 'micrographs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{S}x{S} crop of micrograph 0 through the oracle (torch-CPU convs, C NMS), '
-                      f'times {parts} scaled by processed-pixel ratio to {args.size}x{args.size}'}
+            'cpu': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
+            'sample': sample + '; oracle = torch-CPU fp32 convs (oneDNN), C NMS'}
+
+
+def measured_traffic(dom_name: str, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_dominant.json, written by
+    tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of this same bench command,
+    corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the process, so the
+    figure is only reported when that file describes exactly this kernel and image size -- otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_dominant.json')
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if rec.get('kernel') != dom_name or rec.get('size') != args.size or rec.get('workload') != args.workload:
+        return None, None
+    return rec.get('traffic_bytes_per_launch'), {k: rec.get(k) for k in (
+        'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'algorithmic_bytes', 'source', 'correction')}
+
+
+def dry_run(args, rank, world):
+    """CPU-only plumbing check (no hot path, not a measurement): fabricated pick tables through the same barriers,
+    max-over-ranks reduction and gather as the real run, over gloo."""
+    from topaz_amd import parallel
+    dev = torch.device('cpu')
+    ids = [rank + i * world for i in range(args.steps)]
+    scs, cds = [], []
+    for i in ids:
+        rs = np.random.RandomState(100 + i)
+        n = int(rs.randint(1, 50))
+        scs.append(torch.from_numpy(np.sort(rs.randn(n).astype(np.float32))[::-1].copy()))
+        cds.append(torch.from_numpy(rs.randint(0, args.size, size=(n, 2)).astype(np.int32)))
+    parallel.barrier(dev)
+    t0 = time.perf_counter()
+    tables = parallel.gather_pick_tables(ids, scs, cds, dev) if world > 1 else {i: None for i in ids}
+    parallel.barrier(dev)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        assert sorted(tables) == list(range(world * args.steps)), sorted(tables)
+        print(json.dumps({'dry_run': True, 'metric': 'none (plumbing check, no hot path)', 'value': None, 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'images_gathered': len(tables),
+                          'ms_per_step': 1e3 * dt / max(1, args.steps), 'backend': 'gloo'}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def pcie_inclusive(models, host_imgs, args, dev, n=4):
+    """The same step with the micrograph starting in (pinned) host memory and the pick table ending there: the H2D copy
+    of micrograph i+1 runs on a copy stream under the compute of micrograph i (two device buffers), the picks come back
+    with a synchronous D2H (NMS synchronises anyway to learn the pick count).  File I/O excluded."""
+    S = args.size
+    pinned = [torch.from_numpy(h).pin_memory() for h in host_imgs[:2]]
+    bufs = [torch.empty((S, S), dtype=torch.float32, device=dev) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    main_stream = torch.cuda.current_stream(dev)
+
+    def submit(i):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[i % 2])                      # the step that last read this buffer is finished
+            bufs[i % 2].copy_(pinned[i % 2], non_blocking=True)
+            ready[i % 2].record(copy_stream)
+
+    for e in done:
+        e.record(main_stream)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    submit(0)
+    n_out = 0
+    for i in range(n):
+        if i + 1 < n:
+            submit(i + 1)
+        main_stream.wait_event(ready[i % 2])
+        sc, co = run_step(models, bufs[i % 2], args)
+        done[i % 2].record(main_stream)
+        if co is not None:
+            n_out += int(sc.cpu().numel()) + int(co.cpu().numel())
+        else:
+            n_out += int(sc.cpu().numel())                           # denoise-only workload: the image comes back
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter() - t0
+    return {'value': n / t, 'ms_per_step': 1e3 * t / n, 'steps': n, 'unit': 'micrographs/s',
+            'note': 'input in pinned host memory (H2D of the next micrograph under the compute of this one), pick table '
+                    'copied back to the host; file I/O excluded'}
+
+
+def timed_steps(models, imgs, args, dev, n):
+    """n steps bracketed by device synchronisation; returns (seconds, pick tables)"""
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out = [run_step(models, imgs[i % len(imgs)], args) for i in range(n)]
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0, out
 
 
 def main():
@@ -117,128 +233,87 @@ def main():
     ap.add_argument('--radius', type=int, default=14)
     ap.add_argument('--threshold', type=float, default=-6.0)
     ap.add_argument('--cpu-sample', type=int, default=1024)
-    ap.add_argument('--lanes', type=int, default=1, help='micrographs in flight per GPU (host threads / HIP streams)')
+    ap.add_argument('--cpu-full', action='store_true', help='cpu_baseline on one whole micrograph instead of a crop (minutes)')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the exact_fp32 and pcie_inclusive legs')
+    ap.add_argument('--exact-steps', type=int, default=3)
+    ap.add_argument('--dry-run', action='store_true', help='CPU-only plumbing check over gloo (no hot path, not a measurement)')
     args = ap.parse_args()
 
     from topaz_amd import parallel
-    rank, local_rank, world = parallel.init_from_env()
-    assert world == args.gpus or world == 1, f'WORLD_SIZE={world} but --gpus {args.gpus}'
+    if args.gpus > 1 and not parallel.under_launcher():
+        # plain `python bench.py --gpus N`: be the launcher -- one rank process per GPU, rank 0 prints the line
+        sys.exit(parallel.launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    rank, local_rank, world = parallel.init_from_env('gloo' if args.dry_run else None)
+    assert world == args.gpus, f'WORLD_SIZE={world} but --gpus {args.gpus}'
+    if args.dry_run:
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    from topaz_amd.runtime import get_context
-    ctx = get_context(local_rank)
+    from topaz_amd import runtime as rt
+    ctx = rt.get_context(local_rank)
 
     # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world)
-    n_img = args.steps + args.warmup * args.lanes
-    imgs = [torch.from_numpy(np.random.RandomState(1000 + rank + i * world).randn(args.size, args.size)
-                             .astype(np.float32)).to(dev) for i in range(n_img)]
+    n_img = args.steps + args.warmup
+    host_imgs = [np.random.RandomState(1000 + rank + i * world).randn(args.size, args.size).astype(np.float32)
+                 for i in range(n_img)]
+    imgs = [torch.from_numpy(h).to(dev) for h in host_imgs]
+    models = build_models(args.workload)
+    for w in range(args.warmup):
+        run_step(models, imgs[args.steps + w], args)
+    torch.cuda.synchronize(dev)
+    if not args.no_kernel_timing:
+        # roofline evidence: HIP events around the convolution launches of the TIMED steps (those of >= 20 GFLOP: ~170 of
+        # ~700 launches per step, > 95 % of the kernel time), recorded on the stream the kernels are launched on and
+        # resolved only after the timed region; costs < 0.5 % of the step
+        ctx.prof_enable(2)
+        ctx.prof_reset()
 
-    # Lanes: `--lanes L` host threads, each with its own tpz context (stream + workspace) and model copies,
-    # keep L micrographs in flight on the GPU; steps are dealt round-robin, exactly K steps are timed.
-    import threading
-    from topaz_amd import runtime as rt
-    start = threading.Barrier(args.lanes + 1)
-    ready = threading.Barrier(args.lanes + 1)
-    lane_models, results, errors = [None] * args.lanes, [[] for _ in range(args.lanes)], []
-    lane_stats = [None] * args.lanes       # per-lane HIP-event statistics of the launches of the timed steps
-
-    def lane_main(k):
-        try:
-            torch.cuda.set_device(local_rank)
-            rt.set_lane(k)
-            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                lane_models[k] = build_models(args.workload)
-                for w in range(args.warmup):
-                    run_step(lane_models[k], imgs[args.steps + k * args.warmup + w], args)
-                torch.cuda.current_stream().synchronize()
-                lctx = rt.get_context(local_rank)
-                if not args.no_kernel_timing:
-                    # roofline evidence: HIP events around the convolution launches of the TIMED steps (those of
-                    # >= 20 GFLOP: ~170 of ~700 launches per step, > 95 % of the kernel time), recorded on this lane's
-                    # own stream and resolved only after the timed region; costs ~0.4 % of the step
-                    lctx.prof_enable(2)
-                    lctx.prof_reset()
-                ready.wait()
-                start.wait()
-                for i in range(k, args.steps, args.lanes):
-                    s, c = run_step(lane_models[k], imgs[i], args)
-                    if c is not None:
-                        results[k].append((rank + i * world, s, c))
-                torch.cuda.current_stream().synchronize()
-                lane_stats[k] = (lctx, )
-        except BaseException as e:          # surface worker failures in the main thread
-            errors.append(e)
-            for b in (ready, start):
-                try:
-                    b.abort()
-                except Exception:
-                    pass
-
-    threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(args.lanes)]
-    for t in threads:
-        t.start()
-    try:
-        ready.wait()
-    except threading.BrokenBarrierError:
-        pass
-    if errors:
-        raise errors[0]
+    # ---- the timed region: barrier + synchronize on both sides, exactly K steps, then the one exchange step
     torch.cuda.synchronize(dev)
     parallel.barrier(dev)
     t0 = time.perf_counter()
-    start.wait()
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    picks = sorted((r for lane in results for r in lane), key=lambda r: r[0])
-    ids, scs, cds = [p[0] for p in picks], [p[1] for p in picks], [p[2] for p in picks]
-    if ids and world > 1:
-        parallel.gather_pick_tables(ids, scs, cds, dev)       # the one RCCL exchange step
+    picks = [run_step(models, imgs[i], args) for i in range(args.steps)]
     torch.cuda.synchronize(dev)
+    t_compute = time.perf_counter() - t0
+    ids = [rank + i * world for i in range(args.steps)]
+    scs, cds = [p[0] for p in picks], [p[1] for p in picks]
+    have_picks = cds[0] is not None
+    if have_picks and world > 1:
+        parallel.gather_pick_tables(ids, scs, cds, dev)       # RCCL: all_gather of counts + two gathers to rank 0
+    torch.cuda.synchronize(dev)
+    t_gather = time.perf_counter() - t0 - t_compute
     parallel.barrier(dev)
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
-    n_picks = int(sum(int(s.numel()) for s in scs)) if scs else 0
-    models = lane_models[0]
-    rt.set_lane(0)
+    t_gather = parallel.max_over_ranks(t_gather, dev)
+    n_picks = int(sum(int(s.numel()) for s in scs)) if have_picks else 0
 
-    # ---- roofline: per-kernel HIP-event times of the launches of the timed steps (all lanes), per step
+    # ---- roofline: per-kernel HIP-event times of the launches of the timed steps, per step
     merged, other, conv_ms, conv_n, conv_flops = {}, {'conv_direct_ms': 0.0, 'elementwise_ms': 0.0, 'nms_ms': 0.0}, 0.0, 0, 0.0
+    n_prof_steps = args.steps
     if args.no_kernel_timing:
-        # no events in the timed region: time one extra step on its own stream instead
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-            c0 = get_context(local_rank)
-            c0.prof_enable(True)
-            c0.prof_reset()
-            run_step(models, imgs[-1], args)
-            torch.cuda.current_stream().synchronize()
-        stat_ctxs, n_prof_steps = [c0], 1
-    else:
-        stat_ctxs, n_prof_steps = [st[0] for st in lane_stats if st], args.steps
-    for c in stat_ctxs:
-        for name, ms, n, fl in c.prof_kernels():
-            m0 = merged.setdefault(name, [0.0, 0, 0.0])
-            m0[0] += ms; m0[1] += n; m0[2] += fl
-        ms, n, fl = c.prof_get(0)
-        conv_ms += ms; conv_n += n; conv_flops += fl
-        for k, key in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms')):
-            other[key] += c.prof_get(k)[0]
-        c.prof_enable(False)
+        # no events in the timed region: time one extra step instead
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        run_step(models, imgs[-1], args)
+        torch.cuda.synchronize(dev)
+        n_prof_steps = 1
+    for name, ms, n, fl in ctx.prof_kernels():
+        m0 = merged.setdefault(name, [0.0, 0, 0.0])
+        m0[0] += ms; m0[1] += n; m0[2] += fl
+    conv_ms, conv_n, conv_flops = ctx.prof_get(0)
+    for k, key in ((1, 'conv_direct_ms'), (2, 'elementwise_ms'), (3, 'nms_ms')):
+        other[key] += ctx.prof_get(k)[0]
+    ctx.prof_enable(False)
     kernels = sorted(((nm, v[0] / n_prof_steps, v[1] / n_prof_steps, v[2] / n_prof_steps) for nm, v in merged.items()),
                      key=lambda r: -r[1])                    # (name, ms per step, launches per step, FLOP per step)
     conv_ms, conv_n, conv_flops = conv_ms / n_prof_steps, conv_n / n_prof_steps, conv_flops / n_prof_steps
     other = {k: v / n_prof_steps for k, v in other.items()}
     dom_name, dom_ms, dom_n, dom_flops = kernels[0] if kernels else ('', 0.0, 0, 0.0)
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the value is the one
-    # measured for exactly this kernel and shape with separate rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE, raw,
-    # profiles/r01_split_head_pmc.txt); null for any other configuration
-    traffic = None
-    if dom_name.startswith('conv_split_kernel<K=5x5,D=4,MT=128') and args.size == 4096 and args.workload != 'denoise':
-        traffic = 14.6e9 + 2.68e9
+    traffic, traffic_detail = measured_traffic(dom_name, args)
     is_split = dom_name.startswith('conv_split')
     peak = SPLIT_PEAK_TFLOPS if is_split else FP32_MFMA_PEAK_TFLOPS
 
@@ -250,6 +325,21 @@ def main():
     cls_f32, cls_split = klass('conv_mfma'), klass('conv_split')
     cls_f32['frac'] = cls_f32['achieved'] / FP32_MFMA_PEAK_TFLOPS
     cls_split['frac'] = cls_split['achieved'] / SPLIT_PEAK_TFLOPS
+
+    # ---- extra legs (after the timed region, N = 1 only): exact-fp32 kernels; host-resident input (PCIe-inclusive)
+    extras = {}
+    if world == 1 and not args.no_extras:
+        ctx.set_exact(True)
+        try:
+            run_step(models, imgs[0], args)
+            t, _ = timed_steps(models, imgs, args, dev, args.exact_steps)
+        finally:
+            ctx.set_exact(False)
+        extras['exact_fp32'] = {'value': args.exact_steps / t, 'ms_per_step': 1e3 * t / args.exact_steps,
+                                'steps': args.exact_steps, 'unit': 'micrographs/s',
+                                'note': 'every convolution on the fp32-MFMA kernels (tpz_ctx_set_exact): exact fp32 '
+                                        'multiplies, peak 157.3 TFLOP/s'}
+        extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
 
     if rank == 0:
         out = {
@@ -266,27 +356,27 @@ def main():
             'dtype': 'f32 (fp32 MFMA kernels only: TPZ_EXACT_FP32 is set)' if os.environ.get('TPZ_EXACT_FP32') else
                      'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
                      'multiply-add accumulated in f32 -- fp32-level error, fp32-MFMA re-run on f16-range overflow; '
-                     '1-channel stems, the 1-output-channel last conv and NMS in fp32)',
+                     'NMS in fp32; the exact-fp32-multiply rate is reported as exact_fp32)',
             'data': 'synthetic (N(0,1) micrographs seed 1000+i; seeded random weights of the named architectures)',
             'config': {
                 'workload': {'pipeline': 'denoise(unet b11/t5 nf48, -s 1024 -p 500) -> score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'extract': 'score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'denoise': 'denoise(unet b11/t5 nf48, -s 1024 -p 500)'}[args.workload],
-                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps, 'lanes_per_gpu': args.lanes,
+                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps,
                 'parallelism': f'one micrograph per rank x{world}; RCCL gather of pick tables',
-                'picks_per_image': n_picks / max(1, len(scs)) if scs else None,
+                'picks_per_image': n_picks / max(1, len(scs)) if have_picks else None,
             },
-            # the dominant kernel = the conv instantiation with the most time in a step (live HIP-event timing, one
-            # profiled step on the kernel's own stream); `achieved` is algorithmic (fp32-equivalent) FLOP/s
+            'gather_ms': 1e3 * t_gather,
+            # the dominant kernel = the conv instantiation with the most time in a step (live HIP-event timing of the
+            # timed steps' own launches); `achieved` is algorithmic (fp32-equivalent) FLOP/s
             'roofline': {
                 'bound': 'mfma', 'kernel': dom_name,
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                'traffic_note': 'HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, raw) from profiles/r01_split_head_pmc.txt; '
-                                'algorithmic bytes 8.7e9',
+                'traffic_detail': traffic_detail,
                 'peak_basis': ('f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC (2xf16 split)'
                                if is_split else 'fp32 MFMA peak'),
                 'launches_per_step': dom_n, 'avg_launch_ms': dom_ms / max(1e-9, dom_n),
-                'timed_over': ('the timed steps themselves (HIP events on each lane\'s stream)' if not args.no_kernel_timing
+                'timed_over': ('the timed steps themselves (HIP events on the launch stream)' if not args.no_kernel_timing
                                else 'one extra step after the timed region'),
                 'algorithmic_tflop_per_launch': dom_flops / max(1e-9, dom_n) / 1e12,
                 'share_of_step': dom_ms / (1e3 * dt / args.steps) if dt > 0 else None,
@@ -298,6 +388,7 @@ def main():
                 'coverage': ('convolution launches of >= 20 GFLOP (the rest, elementwise and NMS kernels are not timed inside '
                              'the timed region)' if not args.no_kernel_timing else 'every launch of one extra step'),
             },
+            **extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(models, args)

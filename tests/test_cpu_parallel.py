@@ -74,3 +74,36 @@ def test_gather_single_process():
     s, c = _tables(3)
     out = gather_pick_tables([3], [s], [c], torch.device('cpu'))
     assert torch.equal(out[3][0], s) and torch.equal(out[3][1], c)
+
+
+def test_bench_self_launches_its_ranks_dry_run():
+    """plain `python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) starts its own two rank processes and rank 0
+    prints ONE JSON line with n_gpus = 2; --dry-run replaces the hot path (no GPU here) by fabricated pick tables that
+    go through the same barriers / max-over-ranks / gather over gloo"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-run'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['images_gathered'] == 6 and out['dry_run'] is True
+
+
+def test_launch_local_ranks_propagates_failure():
+    import sys
+    from topaz_amd.parallel import launch_local_ranks
+    code = ('import os, sys, time\n'
+            'r = int(os.environ["RANK"]); assert os.environ["WORLD_SIZE"] == "2" and os.environ["LOCAL_RANK"] == str(r)\n'
+            'assert os.environ["MASTER_ADDR"] == "127.0.0.1"\n'
+            'if r == 1: sys.exit(3)\n'
+            'time.sleep(60)\n')
+    import time
+    t0 = time.time()
+    assert launch_local_ranks(2, [sys.executable, '-c', code]) == 3        # rank 0 is terminated, not waited for
+    assert time.time() - t0 < 30
+    assert launch_local_ranks(2, [sys.executable, '-c', 'import os; assert "RANK" in os.environ']) == 0

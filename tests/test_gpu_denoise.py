@@ -1,6 +1,6 @@
 """U-Net / FCNN / affine denoising on the MI355X against the reference's golden outputs and the
-CPU oracle.  Tolerance 1e-4 on pixels of normalised scale (inputs here are x*3+10, so the
-comparison is done on (y-10)/3)."""
+CPU oracle.  Tolerance: 1e-4 ABSOLUTE on the denoised pixels as returned (BASELINE.json north_star), also where the
+inputs are x*3+10 or x*2+5."""
 import numpy as np
 import pytest
 import torch
@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ATOL = 1e-4
 
 
-def _err(a, b, scale=1.0):
-    return np.abs(a - b).max() / scale
+def _err(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max()
 
 
 @pytest.mark.parametrize('name', ['unet-v0.2.1', 'unet-small', 'fcnn', 'affine'])
@@ -22,8 +22,8 @@ def test_pretrained_vs_reference_golden(gpu_ctx, name):
     z = load_golden('denoise2d_pretrained')
     d = Denoise(name)
     x = z['x']
-    assert _err(d.denoise(x, patch_size=-1), z[f'{name}:whole'], 3.0) <= ATOL
-    assert _err(d.denoise(x, patch_size=64, padding=24), z[f'{name}:p64_24'], 3.0) <= ATOL
+    assert _err(d.denoise(x, patch_size=-1), z[f'{name}:whole']) <= ATOL
+    assert _err(d.denoise(x, patch_size=64, padding=24), z[f'{name}:p64_24']) <= ATOL
 
 
 def test_denoise_image_variants_vs_reference_golden(gpu_ctx):
@@ -32,12 +32,12 @@ def test_denoise_image_variants_vs_reference_golden(gpu_ctx):
     z = load_golden('denoise2d_pretrained')
     x = z['x']
     d = Denoise('unet-v0.2.1')
-    assert _err(denoise_image(x.copy(), [d], patch_size=96, padding=16), z['image:unet-v0.2.1:p96_16'], 3.0) <= ATOL
+    assert _err(denoise_image(x.copy(), [d], patch_size=96, padding=16), z['image:unet-v0.2.1:p96_16']) <= ATOL
     assert _err(denoise_image(x.copy(), [d], patch_size=-1, normalize=True), z['image:unet-v0.2.1:norm']) <= ATOL
     g = GaussianDenoise(1.2)
-    assert _err(g.apply(x), z['gaus1.2:apply'], 3.0) <= ATOL
-    assert _err(denoise_image(x.copy(), [Denoise('unet-small')], gaus=g), z['image:unet-small:gaus1.2'], 3.0) <= ATOL
-    assert _err(denoise_image(x.copy(), [Denoise('affine')], cutoff=1.5), z['image:affine:cutoff'], 3.0) <= ATOL
+    assert _err(g.apply(x), z['gaus1.2:apply']) <= ATOL
+    assert _err(denoise_image(x.copy(), [Denoise('unet-small')], gaus=g), z['image:unet-small:gaus1.2']) <= ATOL
+    assert _err(denoise_image(x.copy(), [Denoise('affine')], cutoff=1.5), z['image:affine:cutoff']) <= ATOL
 
 
 def test_seeded_v022_arch_vs_reference_golden(gpu_ctx):
@@ -66,8 +66,8 @@ def test_denoise3d_vs_reference_golden(gpu_ctx):
     from topaz_amd.denoising.models import DenoiseNet
     z = load_golden('denoise3d_unet3d_nf8')
     d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
-    assert _err(d.denoise(z['tomo'], 32, 16, verbose=False), z['p32_16'], 2.0) <= ATOL
-    assert _err(d.denoise(z['small'], -1, verbose=False), z['small_whole'], 2.0) <= ATOL
+    assert _err(d.denoise(z['tomo'], 32, 16, verbose=False), z['p32_16']) <= ATOL
+    assert _err(d.denoise(z['small'], -1, verbose=False), z['small_whole']) <= ATOL
 
 
 def test_user_model_pickle(gpu_ctx):
@@ -91,7 +91,7 @@ def test_unet3d_nf48_tile_vs_oracle(gpu_ctx):
     assert _err(d.denoise(v, -1, verbose=False), ref) <= ATOL
     t = np.random.RandomState(2001).randn(30, 40, 50).astype(np.float32) * 2 + 3
     ref = oden.denoise3d(sd, t, 32, 16)
-    assert _err(d.denoise(t, 32, 16, verbose=False), ref, 2.0) <= ATOL
+    assert _err(d.denoise(t, 32, 16, verbose=False), ref) <= ATOL
 
 
 def test_full_size_4096_default_patching_vs_oracle_patch(gpu_ctx):
@@ -108,7 +108,7 @@ def test_full_size_4096_default_patching_vs_oracle_patch(gpu_ctx):
         si, ei, sj, ej = max(0, i - 500), min(4096, i + 1524), max(0, j - 500), min(4096, j + 1524)
         ref = oden.denoise_whole('unet', oden.to_torch_sd(sd), torch.from_numpy(x[si:ei, sj:ej].copy()))
         ref = ref[i - si:i - si + 1024, j - sj:j - sj + 1024]
-        assert _err(y[i:i + 1024, j:j + 1024], ref, 2.0) <= ATOL, (i, j)
+        assert _err(y[i:i + 1024, j:j + 1024], ref) <= ATOL, (i, j)
 
 
 def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):

@@ -1,7 +1,8 @@
 """The 2xf16 path (topaz_amd/csrc/conv_split.h): every fp32 operand carried as two f16 halves, three exact
-products accumulated in fp32 on v_mfma_f32_16x16x32_f16.  Same tolerance as the fp32 kernels: 1e-4 * (1 + |ref|)
-against torch-CPU fp32 / the oracle; plus a direct comparison with a float64 evaluation showing the error is at
-the fp32 level, and the f16-range fallback."""
+products accumulated in fp32 on v_mfma_f32_16x16x32_f16.  Network-level tests (whole ResNets / U-Nets against the
+oracle) assert the north-star bar, 1e-4 ABSOLUTE (`_abs`); the single-layer unit tests, whose synthetic outputs reach
+|y| ~ 100, use 1e-4 * (1 + |ref|) (`_err`) plus a direct comparison with a float64 evaluation showing the error is
+at the fp32 level; and the f16-range fallback.  The benchmark's own nets at 4096^2: tests/test_gpu_fullsize.py."""
 import numpy as np
 import pytest
 import torch
@@ -15,6 +16,13 @@ def _err(a, b):
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((np.abs(a - b) / (1.0 + np.abs(b))).max())
+
+
+def _abs(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max())
 
 
 def _act(y, slope):
@@ -123,14 +131,14 @@ def test_resnet_u64_runs_split_and_matches_oracle(gpu_ctx, arch, bn):
     y = m(xt)[0, 0].cpu().numpy()
     after = dm.split_stats()
     assert after[1] == before[1] + 1 and after[2] == before[2]
-    assert _err(y, ref) <= 1e-4
+    assert _abs(y, ref) <= 1e-4
     gpu_ctx.set_exact(True)
     try:
         y32 = m(xt)[0, 0].cpu().numpy()
         assert dm.split_stats()[1] == after[1]
     finally:
         gpu_ctx.set_exact(False)
-    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+    assert _abs(y32, ref) <= 1e-4 and _abs(y, y32) <= 1e-4
 
 
 def test_out_of_range_activations_rerun_in_fp32(gpu_ctx):
@@ -174,13 +182,13 @@ def test_unet_denoise_on_split_path_matches_oracle(gpu_ctx, shape):
     y = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
     after = dm.split_stats()
     assert after[1] == before[1] + 1 and after[2] == before[2]
-    assert _err(y, ref) <= 1e-4
+    assert _abs(y, ref) <= 1e-4
     gpu_ctx.set_exact(True)
     try:
         y32 = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
     finally:
         gpu_ctx.set_exact(False)
-    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+    assert _abs(y32, ref) <= 1e-4 and _abs(y, y32) <= 1e-4
 
 
 def test_unet_patched_denoise_split_matches_oracle(gpu_ctx):
@@ -192,7 +200,7 @@ def test_unet_patched_denoise_split_matches_oracle(gpu_ctx):
     x = np.random.RandomState(9).randn(300, 280).astype(np.float32)
     ref = oden.denoise('unet', sd, x, patch_size=128, padding=64)
     y = dn.denoise_device(torch.from_numpy(x).cuda(), 128, 64).cpu().numpy()
-    assert _err(y, ref) <= 1e-4
+    assert _abs(y, ref) <= 1e-4
     assert dn.model.device_model.split_stats()[1] >= 1
 
 
@@ -212,13 +220,13 @@ def test_unet3d_on_split_path_matches_oracle(gpu_ctx):
     y = dm.denoise_3d(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
     after = dm.split_stats()
     assert after[1] == before[1] + 1 and after[2] == before[2]
-    assert _err(y, ref) <= 1e-4
+    assert _abs(y, ref) <= 1e-4
     gpu_ctx.set_exact(True)
     try:
         y32 = dm.denoise_3d(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
     finally:
         gpu_ctx.set_exact(False)
-    assert _err(y32, ref) <= 1e-4 and _err(y, y32) <= 1e-4
+    assert _abs(y32, ref) <= 1e-4 and _abs(y, y32) <= 1e-4
 
 
 @pytest.mark.parametrize('nf,bw,tw', [(24, 7, 3), (40, 11, 5)])
@@ -233,7 +241,7 @@ def test_unet_odd_widths_mixed_paths(gpu_ctx, nf, bw, tw):
     x = np.random.RandomState(nf).randn(192, 160).astype(np.float32)
     ref = oden.denoise('unet', sd, x)
     y = dn.denoise_device(torch.from_numpy(x).cuda(), -1, 0).cpu().numpy()
-    assert _err(y, ref) <= 1e-4
+    assert _abs(y, ref) <= 1e-4
 
 
 def test_conv_split_random_shapes_vs_fp32_kernels(gpu_ctx):

@@ -13,6 +13,8 @@ from typing import Any, Dict, List, Sequence, Tuple
 # (option strings, keyword arguments for add_argument)
 Flag = Tuple[Sequence[str], Dict[str, Any]]
 
+_GPUS: Flag = (('--gpus',), dict(type=int, default=0, help='start this many rank processes, one per MI355X, and shard the '
+                                   'inputs over them (0: a single process, or all GPUs with -d -2)'))
 _THREADS: Flag = (('-j', '--num-threads'), dict(type=int, default=0, help='host threads for torch (0: library default, <0: all cores)'))
 
 EXTRACT: List[Flag] = [
@@ -39,6 +41,7 @@ EXTRACT: List[Flag] = [
     (('--format',), dict(choices=['coord', 'csv', 'star', 'json', 'box'], default='coord', help='pick file format')),
     (('--dims',), dict(type=int, default=2, choices=[2, 3], help='2: micrographs, 3: tomograms')),
     (('-v', '--verbose'), dict(action='store_true', help='progress on stderr')),
+    _GPUS,
 ]
 
 _TRAINING_ONLY = 'training option (not supported on this path)'
@@ -77,6 +80,7 @@ DENOISE: List[Flag] = [
     (('--num-epochs',), dict(type=int, default=100, help=_TRAINING_ONLY)),
     (('--num-workers',), dict(type=int, default=16, help=_TRAINING_ONLY)),
     _THREADS,
+    _GPUS,
 ]
 
 DENOISE3D: List[Flag] = [
@@ -104,7 +108,8 @@ DENOISE3D: List[Flag] = [
     (('-g', '--gaussian'), dict(type=float, default=0, help='sigma of a Gaussian post-filter (raises: a no-op upstream)')),
     (('-s', '--patch-size'), dict(type=int, default=96, help='tile size (<1: whole volume)')),
     (('-p', '--patch-padding'), dict(type=int, default=48, help='halo around each tile')),
-    (('-d', '--device'), dict(type=int, default=-2, help='-2: LOCAL_RANK under torchrun else GPU 0; >=0: that GPU; -1 is an error')),
+    (('-d', '--device'), dict(type=int, default=-2, help='-2: every visible MI355X (one rank process each; LOCAL_RANK when already under a launcher); >=0: that GPU; -1 is an error')),
+    _GPUS,
 ]
 
 SEGMENT: List[Flag] = [
@@ -115,6 +120,7 @@ SEGMENT: List[Flag] = [
     _THREADS,
     (('-p', '--patch-size'), dict(type=int, default=None, help='score in tiles of twice this size (default: whole image)')),
     (('-v', '--verbose'), dict(action='store_true', help='progress on stdout')),
+    _GPUS,
 ]
 
 DOWNSAMPLE: List[Flag] = [

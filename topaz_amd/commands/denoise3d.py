@@ -1,5 +1,6 @@
 """`topaz denoise3d` -- inference flags of topaz/commands/denoise3d.py:14-58.  `-d -2` (all GPUs, DataParallel
-upstream) means here: run under torchrun, one rank per GPU, volumes sharded over ranks."""
+upstream) means here: `topaz` starts one rank process per visible GPU (main._ranks_to_launch; or run it under
+torchrun) and the volumes are sharded over the ranks."""
 import sys
 
 from ..denoise import Denoise3D, denoise_tomogram_stream

@@ -425,6 +425,17 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     for (int n = 0; n < NW; ++n) acc[m][n][0] += (float)ah[m & 1][0] * (float)bh[n][0] + (float)ao[m & 1][1] * (float)bo[n][1];
                 }
             }
+            // Pin the issue order (the machine scheduler otherwise sinks every A-fragment read to just before its first
+            // use and waits lgkmcnt(0) on it: 2 * MW exposed LDS latencies per step): all B fragments + A(0), then per
+            // channel fragment m the reads of A(m + 1) followed by the 3 * NW MFMAs of m, which cover their latency.
+            if constexpr (!(ABL & 16) && !(ABL & 8)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NW + 2, 0);
+#pragma unroll
+                for (int m = 0; m < MW; ++m) {
+                    if (m + 1 < MW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next step has landed
             if constexpr (!(ABL & 4)) __syncthreads();
         }
@@ -434,6 +445,12 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         // all NW pixel fragments are requested back to back before the first is used (the memory latency is
         // paid once per m, not once per fragment), and invalid pixels are handled by clamped addresses +
         // one predicate on the store.
+        // lane coordinates re-derived behind an opaque copy of the thread index: they (and everything computed from
+        // them) would otherwise stay live across the K loop next to the accumulators, and the head variant spilled them
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        const int l15 = tid_e & 15, l4 = (tid_e >> 4) & 3;
+        const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
         const int fz = oz * a.os + ooz;                      // output plane in the full tensor (0 in 2-D)
         const size_t plane_out = (size_t)a.cells_out * a.Dfull * a.Hfull * a.Wfull;
         const size_t plane_res = (size_t)a.cells_out * a.Dres * a.Hres * a.Wres;
@@ -562,6 +579,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     }  // co-group loop
 
     if constexpr (EPI == EPI_HEAD) {
+        int tid_e = threadIdx.x;
+        asm volatile("" : "+v"(tid_e));
+        const int l15 = tid_e & 15, l4 = (tid_e >> 4) & 3;
+        const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const int trow = wave * C::RPW + n / NFC;

@@ -18,7 +18,28 @@ def main(argv=None):
         module.add_arguments(p)
         p.set_defaults(func=module.main)
     args = parser.parse_args(argv)
+    n = _ranks_to_launch(args)
+    if n > 1:
+        # `--gpus N` / `-d -2`: become the launcher -- N rank processes of this same command line, one per GPU; every
+        # command shards its input list over the ranks (parallel.shard_indices), extract gathers the pick tables
+        from . import parallel
+        cmd = [sys.executable, '-m', 'topaz_amd'] + list(sys.argv[1:] if argv is None else argv)
+        return parallel.launch_local_ranks(n, cmd)
     return args.func(args)
+
+
+def _ranks_to_launch(args) -> int:
+    """rank processes to start for this invocation (0 / 1: run in this process).  `--gpus N` asks for N; `-d -2`
+    (the reference's "all GPUs", commands/denoise3d.py:102-103,117-118) for every visible device.  Never inside a
+    rank process (torchrun or our own launcher set WORLD_SIZE)."""
+    from . import parallel
+    if parallel.under_launcher():
+        return 0
+    n = int(getattr(args, 'gpus', 0) or 0)
+    if n == 0 and getattr(args, 'device', 0) == -2:
+        import torch
+        n = torch.cuda.device_count()
+    return n
 
 
 if __name__ == '__main__':

@@ -32,6 +32,64 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def under_launcher() -> bool:
+    """True inside a rank process (torchrun or launch_local_ranks set WORLD_SIZE)"""
+    return 'WORLD_SIZE' in os.environ
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """One process per GPU without an external launcher: start `n` copies of `argv` (a full command line, e.g.
+    [sys.executable, 'bench.py', '--gpus', '8']) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
+    rank r on GPU r, all on 127.0.0.1.  stdout / stderr are inherited, so rank 0's output is the job's output.
+    Returns the largest exit code; when a rank fails the others are terminated (a hung collective would otherwise
+    wait for its peer forever).  The counterpart of the reference's `-d -2` "use every GPU" (commands/denoise3d.py:
+    102-103,117-118 -- DataParallel threads there, processes over RCCL here)."""
+    import subprocess
+    import time
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e))
+    t0 = time.time()
+    codes: List[Optional[int]] = [None] * n
+    try:
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed or (timeout is not None and time.time() - t0 > timeout):
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = p.wait(10)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[r] = p.wait()
+                return max([abs(c) for c in failed] or [124])
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return max(abs(c) for c in codes)
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """items processed by `rank`: i = rank (mod world), in input order"""
     return list(range(rank, n_items, world))
