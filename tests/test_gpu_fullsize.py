@@ -109,13 +109,13 @@ def test_bench_unet_nf48_4096_default_patching_vs_oracle_patches(gpu_ctx):
         assert e <= ATOL, (i, j, e)
 
 
-def _picks_equivalent(s, c, so, co, ref_map, r, tol):
+def _picks_equivalent(s, c, so, co, ref_map, r, tol, thr=-6.0):
     """pick tables identical, or every differing pick explained by a competitor within `tol` of it in the oracle's map"""
     got, want = set(map(tuple, np.asarray(c).tolist())), set(map(tuple, np.asarray(co).tolist()))
     H, W = ref_map.shape
     for (px, py) in got ^ want:
         win = ref_map[max(0, py - r):py + r + 1, max(0, px - r):px + r + 1]
-        near_thr = abs(ref_map[py, px] - (-6.0)) < tol
+        near_thr = abs(ref_map[py, px] - thr) < tol
         assert near_thr or np.sort(win.ravel())[-1] - ref_map[py, px] < tol, (px, py)
     return len(got ^ want), len(want)
 
@@ -140,22 +140,34 @@ def test_chained_config4_denoise_score_nms_vs_oracle_chain(gpu_ctx, nets):
         size, patch, pad, r = 1100, 512, 250, 14
         d, sd_d = _bench_unet()
         m, sd_s = _bench_resnet()
-    x = np.random.RandomState(1000).randn(size, size).astype(np.float32)
+    rs = np.random.RandomState(1000)
+    x = rs.randn(size, size).astype(np.float32)
+    # dark blobs ("particles") under the noise, so that the pretrained detector has something to find after denoising
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    for cy, cx in rs.randint(40, size - 40, size=(120, 2)):
+        x -= 2.5 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 9.0 ** 2)).astype(np.float32)
+    # oracle chain
+    den_ref = oden.denoise('unet', sd_d, x, patch, pad)
+    log_ref = oscoring.score('resnet8', sd_s, den_ref)
+    # threshold: the CLI default -6 where the map has enough candidates above it, else the map's own 90 % quantile
+    thr = -6.0 if (log_ref > -6.0).mean() > 0.02 else float(np.float32(np.quantile(log_ref, 0.9)))
+    so, co = onms.nms2d(log_ref, r, thr)
+    assert len(so) > 50, (len(so), thr)
     # device chain
     den = d.denoise_device(torch.from_numpy(x).cuda(), patch, pad)
     logits = m(den[None, None])[0, 0]
-    s, c = non_maximum_suppression(logits, r, threshold=-6.0)
-    # oracle chain
-    den_ref = oden.denoise('unet', sd_d, x, patch, pad)
-    assert _abs(den, den_ref) <= ATOL
-    log_ref = oscoring.score('resnet8', sd_s, den_ref)
-    assert _abs(logits, log_ref) <= ATOL
-    so, co = onms.nms2d(log_ref, r, -6.0)
-    assert len(so) > 50
-    n_diff, n = _picks_equivalent(s, c, so, co, log_ref, r, 2 * ATOL)
+    s, c = non_maximum_suppression(logits, r, threshold=thr)
+    e_den, e_log = _abs(den, den_ref), _abs(logits, log_ref)
+    # stage parity on identical inputs (score of the DEVICE's denoised image vs the oracle scoring that same image) ...
+    e_stage = _abs(logits, oscoring.score('resnet8', sd_s, den.cpu().numpy()))
+    print(f'chain[{nets}] {size}^2: |den| {e_den:.2e}  |logit| chain {e_log:.2e} stage {e_stage:.2e}  picks {len(so)} thr {thr:.3f}')
+    assert e_den <= ATOL and e_stage <= ATOL
+    # ... and the chain end to end: the 1e-4 of the first stage passes through the second
+    assert e_log <= ATOL
+    n_diff, n = _picks_equivalent(s, c, so, co, log_ref, r, 2 * ATOL, thr)
     assert n_diff <= max(2, n // 100), (n_diff, n)
     # NMS of the oracle's own map on the device is bit-exact
-    s2, c2 = non_maximum_suppression(log_ref, r, threshold=-6.0)
+    s2, c2 = non_maximum_suppression(log_ref, r, threshold=thr)
     assert np.array_equal(c2, co) and np.array_equal(s2, so)
 
 

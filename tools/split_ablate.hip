@@ -39,8 +39,8 @@ int bench(const char* name, int cin, int cout, int H) {
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;
     CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
-    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 16));
-    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 16));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 64));
+    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 64));
     // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
     std::vector<uint16_t> h(1 << 21);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x2800 + ((i * 2654435761u) >> 20) % 0x1000) | (uint16_t)(((i * 40503u) >> 7) & 1) << 15;
@@ -61,16 +61,21 @@ int bench(const char* name, int cin, int cout, int H) {
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
            n_st * a.cog_inner);
-#define RUN(ABL, label) { float ms = run<C, EPI, ABL>(a, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", label, ms, tf / (ms * 1e-3)); }
+#define RUN(ABL, label) { hipMemset(flag, 0, 64); float ms = run<C, EPI, (ABL) | 2048>(a, grid, 6); unsigned long long c[4]; hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost); \
+    printf("  %-52s %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", label, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0); }
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
-    { SplitArgs b = a; b.issuer_half = 1; float ms = run<C, EPI, 0>(b, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", "upper half of the waves issues all DMA", ms, tf / (ms * 1e-3)); }
-    { SplitArgs b = a; b.issuer_half = 1; float ms = run<C, EPI, 0>(b, grid, 3); printf("  %-52s %8.3f ms  %6.1f TF/s\n", "upper half issues all DMA (again)", ms, tf / (ms * 1e-3)); }
+    { SplitArgs a0 = a; a.issuer_half = 1; RUN(0, "upper half of the waves issues all DMA"); RUN(0, "upper half issues all DMA (again)"); a = a0; }
     RUN(0, "baseline (third)");
     RUN(1, "no epilogue loads/stores");
     RUN(32, "no residual loads");
     RUN(64, "no stores");
     RUN(2, "no per-step DMA issue");
+    RUN(128, "no per-step WEIGHT DMA (input DMA kept)");
+    RUN(256, "no per-step INPUT DMA (weight DMA kept)");
+    RUN(4096, "input DMA from contiguous addresses, no offset table");
+    RUN(8192, "input DMA from an L2-resident 2 MB window");
+    RUN(8192 | 4096, "input DMA contiguous + L2-resident");
     RUN(4, "no per-step barrier");
     RUN(8, "A fragments read once per step");
     RUN(1 | 2, "no epilogue, no DMA");

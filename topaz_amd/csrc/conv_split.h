@@ -174,6 +174,10 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 // ABL: timing-ablation switches for tools/split_ablate.hip only (production kernels use ABL = 0; results are not
 // meaningful otherwise):  1 no epilogue loads / stores   2 no per-step DMA issue   4 no per-step barrier
 //   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs   32 no residual loads   64 no stores
+//   128 no per-step weight DMA   256 no per-step input DMA
+//   4096 input DMA without the offset table (contiguous dummy source)   8192 input DMA from a 2 MB window (always L2 hits)
+//   2048 clock probe: every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
+//        to the two 64-bit counters behind a.flag -> effective clock of the variant (DVFS: the chip runs at its power limit)
 template <class C, int EPI, int ABL = 0>
 __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
@@ -182,6 +186,11 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     unsigned* lds_slot = reinterpret_cast<unsigned*>(lds + C::OFF_SLOT);
 
     const int tid = threadIdx.x;
+    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    if constexpr ((ABL & 2048) != 0) {
+        probe_c0 = __builtin_readcyclecounter();
+        probe_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -258,9 +267,11 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const bool second = ch >= chunks1;
             const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * a.Hin * a.Win
                                         : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
+            if constexpr ((ABL & 8192) != 0) chunk = a.in;            // (ABL 8192: every tile reads one L2-resident window)
             const void* bhi = uniform_ptr(vol ? a.in : chunk);
-            const void* blo = uniform_ptr((vol ? a.in : chunk) + (second ? plane2 : plane1));
-            unsigned off = lds_tab[g];
+            const void* blo = uniform_ptr((vol ? a.in : chunk) + ((ABL & 8192) ? (size_t)0x20000 : second ? plane2 : plane1));
+            unsigned off = (ABL & 4096) ? (unsigned)g * 16u : lds_tab[g];      // (ABL 4096: no table, contiguous source)
+            if constexpr ((ABL & 8192) != 0) off = off == OOB ? off : (off & 0x1ffff0u);
             bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
             if (!vol) {
                 if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
@@ -338,6 +349,40 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // LDS address of this lane's B fragments of step st (its slot of the step: tap + cell of the chunk's tile)
+        auto b_frag_base = [&](int st) -> const unsigned char* {
+            if constexpr (C::CONT) {
+                int G = 4 * st + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
+                if (cg2 >= n_full) {
+                    // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond
+                    // it the padding slots of the last step (zero weights, any valid address)
+                    const int q2 = G - n_full * C::Q;
+                    cg2 = n_full < a.n_chunks ? n_full : a.n_chunks - 1;
+                    q = (n_rem > 0 && q2 < C::TAPS * n_rem) ? (q2 / n_rem) * C::CC + (q2 % n_rem) : 0;
+                }
+                return lds + (cg2 & 1) * C::IN_BUF + b_lane + lds_slot[q];
+            } else {
+                const int ch = st / C::NSTEP;
+                return lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[(st - ch * C::NSTEP) * 4 + l4];
+            }
+        };
+        // The first fragments of a step -- all its B fragments (hi, lo) and A(0) -- are loop-carried registers: they are
+        // refreshed IN PLACE for step s + 1 during the last channel fragment of step s, each right after the last MFMA
+        // that reads its register has been issued (an MFMA reads its A/B operands at issue; the LDS data lands >= 64
+        // cycles later), so the pipelining across the barrier costs no extra registers and no copies.
+        f16x8 bh[NW], bo[NW], ah[2], ao[2];
+        auto b_off = [&](int n) { return ((n / NFC) * C::ITW + (n % NFC) * 16) * 16; };
+        {
+            const unsigned char* bl = b_frag_base(0);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n));
+                bo[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n) + C::PLANE_BYTES);
+            }
+            ah[0] = *reinterpret_cast<const f16x8*>(lds + a_lane);
+            ao[0] = *reinterpret_cast<const f16x8*>(lds + a_lane + MW * 1024);
+        }
+
 #pragma unroll 1
         for (int s = 0; s < n_stages; ++s) {
             // chunk of the step's first slot; pf = chunk whose tile is being prefetched, r0 / rstride = its DMA rounds
@@ -363,81 +408,106 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 // start their MFMAs at once and keep the matrix core busy meanwhile)
                 const bool iss = a.issuer_half && C::WAVES == 8 && !a.in2;
                 const int reps = iss ? (wave >= 4 ? 2 : 0) : 1;
-                for (int rep = 0; rep < reps; ++rep) {
-                    const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
-                    if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1, vt, vw);
-                    if (pf < a.n_chunks && r0 < C::NR) {
-                        if (r0 == 0 && pf == chunks1) compute_offsets(true);         // switching to the second source
+                if constexpr (!(ABL & 128)) {
+                    for (int rep = 0; rep < reps; ++rep) {
+                        const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
+                        if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1, vt, vw);
+                    }
+                }
+                if (!(ABL & 256) && pf < a.n_chunks && r0 < C::NR) {
+                    if (r0 == 0 && pf == chunks1) compute_offsets(true);         // switching to the second source
+                    for (int rep = 0; rep < reps; ++rep) {
+                        const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
 #pragma unroll 1
-                        for (int r = r0; r < C::NR; r += rstride) issue_input(pf, pf & 1, r, vt, vw);
+                        for (int r = r0; r < C::NR; r += rstride) {
+                            issue_input(pf, pf & 1, r, vt, vw);
+                        }
                     }
                 }
             }
-            // ---- the step's MFMAs
-            const unsigned char* bl;
-            if constexpr (C::CONT) {
-                int G = 4 * s + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
-                if (cg2 >= n_full) {
-                    // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond
-                    // it the padding slots of the last step (zero weights, any valid address)
-                    const int q2 = G - n_full * C::Q;
-                    cg2 = n_full < a.n_chunks ? n_full : a.n_chunks - 1;
-                    q = (n_rem > 0 && q2 < C::TAPS * n_rem) ? (q2 / n_rem) * C::CC + (q2 % n_rem) : 0;
-                }
-                bl = lds + (cg2 & 1) * C::IN_BUF + b_lane + lds_slot[q];
-            } else {
-                bl = lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[(s - ch * C::NSTEP) * 4 + l4];
-            }
+            // ---- the step's MFMAs, register-pipelined across the step barrier:
+            //   channel fragments 0 .. MW-2 (A(m + 1) requested one fragment ahead), then the DMA drain + barrier, then the
+            //   MFMAs of the last channel fragment -- which need registers only -- interleaved with the requests for the
+            //   B fragments and A(0) of step s + 1.  The matrix core is not left idle for an LDS round trip after every
+            //   barrier (150 - 250 cycles of a step of 768 (MT = 64) ... 3072 (MT = 128, 8 waves) cycles).
+            //   MFMA order within a channel fragment: ah*bo, ah*bh, ao*bh -- the lo halves of B are released first.
+            const unsigned char* bl_next = b_frag_base(s + 1 < n_stages ? s + 1 : s);      // (slot-table lookup: early)
             const unsigned char* al = lds + a_lane + (s & 1) * C::W_STEP_BYTES;
-            f16x8 bh[NW], bo[NW];
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                const int off = ((n / NFC) * C::ITW + (n % NFC) * 16) * 16;
-                bh[n] = *reinterpret_cast<const f16x8*>(bl + off);
-                bo[n] = *reinterpret_cast<const f16x8*>(bl + off + C::PLANE_BYTES);
-            }
-            f16x8 ah[2], ao[2];
-            ah[0] = *reinterpret_cast<const f16x8*>(al);
-            ao[0] = *reinterpret_cast<const f16x8*>(al + MW * 1024);
+            const unsigned char* al_next = lds + a_lane + ((s + 1) & 1) * C::W_STEP_BYTES;
+            constexpr bool A0_EARLY = (MW % 2 == 0);          // slot 0 of ah / ao is free during the last fragment (slot 1)
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
+                const int t = m & 1;
                 if (m + 1 < MW) {
                     if constexpr (!(ABL & 8)) {
-                        ah[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
-                        ao[(m + 1) & 1] = *reinterpret_cast<const f16x8*>(al + (MW + m + 1) * 1024);
+                        ah[t ^ 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
+                        ao[t ^ 1] = *reinterpret_cast<const f16x8*>(al + (MW + m + 1) * 1024);
                     } else {
-                        ah[(m + 1) & 1] = ah[m & 1];
-                        ao[(m + 1) & 1] = ao[m & 1];
+                        ah[t ^ 1] = ah[t];
+                        ao[t ^ 1] = ao[t];
                     }
+                } else {
+                    // ---- last channel fragment.  First pin the order of everything above (the machine scheduler otherwise
+                    // sinks every fragment read to just before its first use and waits lgkmcnt(0) on it: 2 * MW exposed
+                    // LDS latencies per step)
+                    if constexpr (!(ABL & 16) && !(ABL & 8)) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // (the slot-table lookup)
+#pragma unroll
+                        for (int mm = 0; mm + 1 < MW; ++mm) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // A(mm + 1)
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);    // MFMAs of mm
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this step has landed
+                    if constexpr (!(ABL & 4)) __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bool last = m + 1 == MW;
+                f16x8 a_hi = ah[t], a_lo = ao[t];
+                if (last && A0_EARLY) {
+                    ah[0] = *reinterpret_cast<const f16x8*>(al_next);
+                    ao[0] = *reinterpret_cast<const f16x8*>(al_next + MW * 1024);
                 }
                 if constexpr (!(ABL & 16)) {
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bo[n], acc[m][n], 0, 0, 0);
+                    if (last) {
+#pragma unroll
+                        for (int n = 0; n < NW; ++n) bo[n] = *reinterpret_cast<const f16x8*>(bl_next + b_off(n) + C::PLANE_BYTES);
+                    }
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m & 1], bo[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
                     for (int n = 0; n < NW; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao[m & 1], bh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh[n], acc[m][n], 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) acc[m][n][0] += (float)ah[m & 1][0] * (float)bh[n][0] + (float)ao[m & 1][1] * (float)bo[n][1];
-                }
-            }
-            // Pin the issue order (the machine scheduler otherwise sinks every A-fragment read to just before its first
-            // use and waits lgkmcnt(0) on it: 2 * MW exposed LDS latencies per step): all B fragments + A(0), then per
-            // channel fragment m the reads of A(m + 1) followed by the 3 * NW MFMAs of m, which cover their latency.
-            if constexpr (!(ABL & 16) && !(ABL & 8)) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NW + 2, 0);
+                    for (int n = 0; n < NW; ++n) acc[m][n][0] += (float)a_hi[0] * (float)bh[n][0] + (float)a_lo[1] * (float)bo[n][1];
+                    if (last) {
 #pragma unroll
-                for (int m = 0; m < MW; ++m) {
-                    if (m + 1 < MW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);
+                        for (int n = 0; n < NW; ++n) bo[n] = *reinterpret_cast<const f16x8*>(bl_next + b_off(n) + C::PLANE_BYTES);
+                    }
+                }
+                if (last) {
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) bh[n] = *reinterpret_cast<const f16x8*>(bl_next + b_off(n));
+                    if (!A0_EARLY) {
+                        ah[0] = *reinterpret_cast<const f16x8*>(al_next);
+                        ao[0] = *reinterpret_cast<const f16x8*>(al_next + MW * 1024);
+                    }
+                    if constexpr (!(ABL & 16) && !(ABL & 8)) {
+                        if (A0_EARLY) __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NW, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NW, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NW, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, A0_EARLY ? NW : NW + 2, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next step has landed
-            if constexpr (!(ABL & 4)) __syncthreads();
         }
 
         // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store.
@@ -578,6 +648,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         }
     }  // co-group loop
 
+    if constexpr ((ABL & 2048) != 0) {
+        if (threadIdx.x == 0) {
+            unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.flag) + 1;
+            atomicAdd(ctr, __builtin_readcyclecounter() - probe_c0);
+            atomicAdd(ctr + 1, __builtin_amdgcn_s_memrealtime() - probe_r0);
+        }
+    }
     if constexpr (EPI == EPI_HEAD) {
         int tid_e = threadIdx.x;
         asm volatile("" : "+v"(tid_e));

@@ -54,6 +54,9 @@ static const bool g_no_phase = getenv("TPZ_NO_PHASE") != nullptr;
 static const bool g_exact_fp32 = getenv("TPZ_EXACT_FP32") != nullptr;
 // TPZ_NO_ISSUER=1: every wave issues its own share of the per-step LDS-DMA (A/B switch for tuning, see launch_split)
 static const bool g_no_issuer = getenv("TPZ_NO_ISSUER") != nullptr;
+static const bool g_no_lanes = getenv("TPZ_NO_LANES") != nullptr;      // patches / tiles of an image on one stream only
+
+enum { NMS_BATCH = 4, NMS_SNAP = 8, NMS_PICKS = 15, NMS_COUNTERS = 16 };
 
 struct ProfRec {
     int cls;
@@ -76,11 +79,27 @@ struct tpz_ctx {
         size_t bytes;
         bool used;
     };
-    std::vector<Buf> pool;
+    std::vector<Buf> pool;        // workspace of the ctx stream
+    std::vector<Buf>* pool_cur = &pool;
+    // Patch lanes: independent patches / tiles of one image are enqueued alternately on two auxiliary streams, each
+    // with its own workspace pool and reduction scratch, so that the small, latency-bound launches of one patch (the
+    // deep U-Net levels: 16-tile grids on 256 CUs) run under the large ones of its neighbour (lanes_begin / lane_enter /
+    // lanes_end).  One host thread enqueues everything; nothing synchronises with the host.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        std::vector<Buf> pool;
+        double* d_part = nullptr;
+    };
+    Lane lanes[2];
+    hipEvent_t lanes_fork = nullptr;
+    hipStream_t lanes_saved_stream = nullptr;
+    double* lanes_saved_part = nullptr;
+    bool lanes_on = false;
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
-    unsigned int* d_counters = nullptr;
+    unsigned int* d_counters = nullptr;     // NMS_COUNTERS entries (nms_common)
     float* d_zeros = nullptr;     // 256 B of zeros: DMA source of padded / out-of-image elements
     unsigned* d_flag = nullptr;   // f16-range overflow flag of the 2xf16 path
     unsigned* h_flag = nullptr;   // pinned copy
@@ -119,40 +138,82 @@ static int fail(tpz_ctx* ctx, const char* fmt, ...) {
 
 static void* pool_alloc(tpz_ctx* ctx, size_t bytes) {
     if (bytes == 0) bytes = 16;
+    std::vector<tpz_ctx::Buf>& pool = *ctx->pool_cur;
     int best = -1;
-    for (int i = 0; i < (int)ctx->pool.size(); ++i) {
-        auto& b = ctx->pool[i];
-        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = i;
+    for (int i = 0; i < (int)pool.size(); ++i) {
+        auto& b = pool[i];
+        if (!b.used && b.bytes >= bytes && (best < 0 || b.bytes < pool[best].bytes)) best = i;
     }
     if (best >= 0) {
-        ctx->pool[best].used = true;
-        return ctx->pool[best].p;
+        pool[best].used = true;
+        return pool[best].p;
     }
     void* p = nullptr;
     // round up so slightly larger requests can reuse the buffer
     size_t rounded = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
     if (hipMalloc(&p, rounded) != hipSuccess) {
         // drop unused cached buffers and retry once
-        for (auto it = ctx->pool.begin(); it != ctx->pool.end();) {
-            if (!it->used) { (void)hipFree(it->p); it = ctx->pool.erase(it); }
+        for (auto it = pool.begin(); it != pool.end();) {
+            if (!it->used) { (void)hipFree(it->p); it = pool.erase(it); }
             else ++it;
         }
         if (hipMalloc(&p, rounded) != hipSuccess) return nullptr;
     }
-    ctx->pool.push_back({p, rounded, true});
+    pool.push_back({p, rounded, true});
     return p;
 }
 static void pool_release(tpz_ctx* ctx, void* p) {
-    for (auto& b : ctx->pool)
+    for (auto& b : *ctx->pool_cur)
         if (b.p == p) { b.used = false; return; }
 }
 
 static float* next_nrm(tpz_ctx* ctx) {
     if (ctx->nrm_next >= NRM_RING) {
-        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->lanes_on) (void)hipDeviceSynchronize();     // the other lane may still read blocks of this ring
+        else (void)hipStreamSynchronize(ctx->stream);
         ctx->nrm_next = 0;
     }
     return ctx->d_nrm + 4 * (ctx->nrm_next++);
+}
+
+// ---- patch lanes (tpz_ctx::Lane)
+static int lanes_begin(tpz_ctx* ctx) {
+    if (g_no_lanes || ctx->lanes_on) return 0;
+    if (!ctx->lanes_fork) {
+        if (hipEventCreateWithFlags(&ctx->lanes_fork, hipEventDisableTiming) != hipSuccess) return fail(ctx, "hipEventCreate failed");
+        for (auto& ln : ctx->lanes) {
+            if (hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess ||
+                hipMalloc((void**)&ln.d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess)
+                return fail(ctx, "patch lanes: stream / event / scratch creation failed");
+        }
+    }
+    // the lanes start after everything already queued on the ctx stream (the input image, the cleared overflow flag)
+    HIPCHK(ctx, hipEventRecord(ctx->lanes_fork, ctx->stream));
+    for (auto& ln : ctx->lanes) HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->lanes_fork, 0));
+    ctx->lanes_saved_stream = ctx->stream;
+    ctx->lanes_saved_part = ctx->d_part;
+    ctx->lanes_on = true;
+    return 0;
+}
+static void lane_enter(tpz_ctx* ctx, int k) {
+    if (!ctx->lanes_on) return;
+    tpz_ctx::Lane& ln = ctx->lanes[k & 1];
+    ctx->stream = ln.stream;
+    ctx->pool_cur = &ln.pool;
+    ctx->d_part = ln.d_part;
+}
+static int lanes_end(tpz_ctx* ctx) {
+    if (!ctx->lanes_on) return 0;
+    ctx->stream = ctx->lanes_saved_stream;
+    ctx->pool_cur = &ctx->pool;
+    ctx->d_part = ctx->lanes_saved_part;
+    ctx->lanes_on = false;
+    for (auto& ln : ctx->lanes) {
+        HIPCHK(ctx, hipEventRecord(ln.done, ln.stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ln.done, 0));
+    }
+    return 0;
 }
 
 // ---- profiling helpers
@@ -1446,7 +1507,7 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (hipMalloc((void**)&ctx->d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_counters, NMS_COUNTERS * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flag, 16) != hipSuccess || hipHostMalloc((void**)&ctx->h_flag, 16) != hipSuccess ||
         hipMalloc((void**)&ctx->d_zeros, 256) != hipSuccess || hipMemset(ctx->d_zeros, 0, 256) != hipSuccess) {
         delete ctx;
@@ -1460,7 +1521,15 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     for (auto& b : ctx->pool) (void)hipFree(b.p);
+    for (auto& ln : ctx->lanes) {
+        for (auto& b : ln.pool) (void)hipFree(b.p);
+        if (ln.d_part) (void)hipFree(ln.d_part);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
+    if (ctx->lanes_fork) (void)hipEventDestroy(ctx->lanes_fork);
     (void)hipFree(ctx->d_part);
     (void)hipFree(ctx->d_nrm);
     (void)hipFree(ctx->d_counters);
@@ -1711,8 +1780,11 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
         set_dense(v, const_cast<float*>(d_in), 1, 1, H, W);
         return denoise_region(m, v, d_out, 1, nullptr, split);
     }
-    for (int i = 0; i < H; i += patch)
-        for (int j = 0; j < W; j += patch) {
+    if (lanes_begin(ctx)) return 1;
+    int rc_all = 0, n_patch = 0;
+    for (int i = 0; i < H && !rc_all; i += patch)
+        for (int j = 0; j < W && !rc_all; j += patch) {
+            lane_enter(ctx, n_patch++);
             const int si = std::max(0, i - pad), ei = std::min(H, i + patch + pad);
             const int sj = std::max(0, j - pad), ej = std::min(W, j + patch + pad);
             const int ph = ei - si, pw = ej - sj;
@@ -1722,7 +1794,7 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
             v.ps = (long long)H * W;
             v.cs = v.ps;
             float* tmp = (float*)pool_alloc(ctx, (size_t)ph * pw * sizeof(float));
-            if (!tmp) return fail(ctx, "out of device memory");
+            if (!tmp) { rc_all = fail(ctx, "out of device memory"); break; }
             int rc = denoise_region(m, v, tmp, 1, nullptr, split);
             if (rc == 0) {
                 const int oi = i - si, oj = j - sj;
@@ -1734,9 +1806,12 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
                 if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
             }
             pool_release(ctx, tmp);
-            if (rc) return rc;
+            if (rc) rc_all = rc;
         }
-    return 0;
+    const std::string err = ctx->err;
+    if (lanes_end(ctx) && !rc_all) rc_all = 1;
+    if (rc_all && !err.empty()) ctx->err = err;
+    return rc_all;
 }
 
 int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int pad, float* d_out) {
@@ -1771,13 +1846,23 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     HIPCHK(ctx, launch_meanstd(d_in, D, H, W, (long long)H * W, W, 0, 0, nullptr, ctx->d_part, PART_BLOCKS, g, ctx->stream));
     const int d = patch + 2 * pad;
     const size_t tn = (size_t)d * d * d;
-    float* tile = (float*)pool_alloc(ctx, tn * sizeof(float));
-    float* tout = (float*)pool_alloc(ctx, tn * sizeof(float));
-    if (!tile || !tout) return fail(ctx, "out of device memory");
+    if (lanes_begin(ctx)) return 1;
+    const int n_lanes = ctx->lanes_on ? 2 : 1;
+    float *tiles[2] = {nullptr, nullptr}, *touts[2] = {nullptr, nullptr};
     int rc = 0;
+    for (int l = 0; l < n_lanes; ++l) {
+        lane_enter(ctx, l);
+        tiles[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
+        touts[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
+        if (!tiles[l] || !touts[l]) rc = fail(ctx, "out of device memory");
+    }
+    int n_tile = 0;
     for (int i = 0; i < D && !rc; i += patch)
         for (int j = 0; j < H && !rc; j += patch)
             for (int k = 0; k < W && !rc; k += patch) {
+                const int l = n_tile++ % n_lanes;
+                lane_enter(ctx, l);
+                float *tile = tiles[l], *tout = touts[l];
                 prof_begin(ctx, 2, 0);
                 hipError_t e = launch_extract_tile3d(d_in, D, H, W, i - pad, j - pad, k - pad, d, g, tile, ctx->stream);
                 prof_end(ctx);
@@ -1793,8 +1878,14 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
                 prof_end(ctx);
                 if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
             }
-    pool_release(ctx, tile);
-    pool_release(ctx, tout);
+    for (int l = 0; l < n_lanes; ++l) {
+        lane_enter(ctx, l);
+        if (tiles[l]) pool_release(ctx, tiles[l]);
+        if (touts[l]) pool_release(ctx, touts[l]);
+    }
+    const std::string err = ctx->err;
+    if (lanes_end(ctx) && !rc) rc = 1;
+    if (rc && !err.empty()) ctx->err = err;
     return rc;
 }
 
@@ -2002,59 +2093,81 @@ int tpz_filter_2d(tpz_ctx* ctx, const float* d_in, int H, int W, const float* h_
 }
 
 // ---- NMS ------------------------------------------------------------------------------------------
+// Device-side counters of one NMS call: [0 .. NMS_BATCH] lengths of the candidate lists (sweep k of a batch reads [k] and
+// appends its leftovers under [k + 1]); [NMS_SNAP + k] picks before sweep k of the batch (the push after sweep k covers
+// keys[snap[k] .. snap[k + 1])); [NMS_PICKS] picks so far.
 static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int dims, int r, const int* h_aux,
-                      int n_aux, float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n) {
+                      int n_aux, int n_aux2, float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n) {
     const size_t n = (size_t)D * H * W;
     if (n >= ((size_t)1 << 32)) return fail(ctx, "nms: more than 2^32 elements");
     hipStream_t s = ctx->stream;
+    // capacity of the pick list: every pick suppresses at least itself and (r >= 1) its row neighbours, but the bound that
+    // always holds is one pick per pixel; keys are only ever touched up to the pick count
+    size_t kcap = 4096;
+    while (kcap < n) kcap <<= 1;
     uint8_t* status = (uint8_t*)pool_alloc(ctx, n);
-    uint32_t* cand = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
-    int* d_aux = (int*)pool_alloc(ctx, std::max(1, n_aux) * sizeof(int));
-    if (!status || !cand || !d_aux) return fail(ctx, "nms: out of device memory");
-    int rc = 0;
-    uint64_t* keys = nullptr;
-    unsigned int hc[4] = {0, 0, 0, 0};
+    uint32_t* listA = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
+    uint32_t* listB = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
+    uint64_t* keys = (uint64_t*)pool_alloc(ctx, kcap * sizeof(uint64_t));
+    int* d_aux = (int*)pool_alloc(ctx, std::max(1, n_aux + n_aux2) * sizeof(int));
     auto done = [&](int code) {
         pool_release(ctx, status);
-        pool_release(ctx, cand);
+        pool_release(ctx, listA);
+        pool_release(ctx, listB);
+        pool_release(ctx, keys);
         pool_release(ctx, d_aux);
-        if (keys) pool_release(ctx, keys);
         return code;
     };
+    if (!status || !listA || !listB || !keys || !d_aux) return done(fail(ctx, "nms: out of device memory"));
+    int rc = 0;
+    unsigned int* cnt = ctx->d_counters;
     prof_begin(ctx, 3, 0);
-    if (hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned int), s) != hipSuccess ||
-        hipMemcpyAsync(d_aux, h_aux, n_aux * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
-        nms_mark(d_score, n, threshold, status, cand, ctx->d_counters, s) != hipSuccess ||
-        hipMemcpyAsync(hc, ctx->d_counters, sizeof hc, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) {
+    auto bail = [&](const char* what, hipError_t e) {
         prof_end(ctx);
-        return done(fail(ctx, "nms: mark phase failed: %s", hipGetErrorString(hipGetLastError())));
-    }
-    const unsigned int ncand = hc[0];
+        return done(fail(ctx, "nms: %s failed: %s", what, hipGetErrorString(e)));
+    };
+    hipError_t e = hipMemsetAsync(cnt, 0, NMS_COUNTERS * sizeof(unsigned int), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_aux, h_aux, (n_aux + n_aux2) * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = nms_mark(d_score, n, threshold, status, listA, cnt, s);       // candidates -> listA, count -> cnt[0]
+    if (e != hipSuccess) return bail("mark phase", e);
+    // Relaxation sweeps until no candidate is undecided.  Every sweep decides at least the highest-priority undecided
+    // candidate, so the candidate count bounds the sweep count; in practice a map needs 5 - 10.  The sweeps of a batch are
+    // queued back to back (their list lengths stay on the device) and one counter is read per batch.
+    unsigned int hc[NMS_COUNTERS];
+    unsigned long long sweeps = 0;
+    unsigned int ncand = 0;
+    bool first_batch = true;
+    size_t hint = n;                         // upper bound of the current list's length (grid sizing only)
+    uint32_t *lin = listA, *lout = listB;
     unsigned int npicks = 0;
-    if (ncand > 0) {
-        // relaxation sweeps until no candidate is undecided; every sweep decides at least the
-        // highest-priority undecided candidate, so ncand sweeps is a hard upper bound.
-        unsigned int remaining = ncand;
-        unsigned long long sweeps = 0;
-        while (remaining > 0) {
-            if (++sweeps > (unsigned long long)ncand + 1) { prof_end(ctx); return done(fail(ctx, "nms: fix-point did not converge")); }
-            hipError_t e = hipMemsetAsync(ctx->d_counters + 1, 0, sizeof(unsigned int), s);
-            if (e == hipSuccess)
-                e = dims == 2 ? nms2d_iter(d_score, H, W, r, d_aux, status, cand, ncand, ctx->d_counters, s)
-                              : nms3d_iter(d_score, (long long)n, d_aux, n_aux, status, cand, ncand, ctx->d_counters, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(&remaining, ctx->d_counters + 1, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: sweep failed: %s", hipGetErrorString(e))); }
+    for (;;) {
+        int k = 0;
+        for (; k < NMS_BATCH; ++k) {
+            e = dims == 2 ? nms2d_sweep(d_score, H, W, r, d_aux, d_aux + n_aux, n_aux2, status, lin, lout, cnt + k, cnt + NMS_SNAP + k,
+                                        keys, cnt + NMS_PICKS, hint, s)
+                          : nms3d_sweep(d_score, (long long)n, d_aux, n_aux, status, lin, lout, cnt + k, cnt + NMS_SNAP + k, keys,
+                                        cnt + NMS_PICKS, hint, s);
+            if (e != hipSuccess) return bail("sweep", e);
+            std::swap(lin, lout);
         }
-        size_t npow2 = 4096;
-        while (npow2 < ncand) npow2 <<= 1;
-        keys = (uint64_t*)pool_alloc(ctx, npow2 * sizeof(uint64_t));
-        if (!keys) { prof_end(ctx); return done(fail(ctx, "nms: out of device memory")); }
-        hipError_t e = nms_gather(d_score, status, cand, ncand, keys, ctx->d_counters, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(&npicks, ctx->d_counters + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+        sweeps += NMS_BATCH;
+        e = hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: gather failed: %s", hipGetErrorString(e))); }
+        if (e != hipSuccess) return bail("sweep batch", e);
+        npicks = hc[NMS_PICKS];
+        const unsigned int remaining = hc[NMS_BATCH];
+        if (remaining == 0) break;
+        if (first_batch) { ncand = hc[0]; first_batch = false; }
+        if (sweeps > 2ull * ncand + NMS_BATCH) { prof_end(ctx); return done(fail(ctx, "nms: fix-point did not converge")); }
+        // next batch: the leftovers are list [NMS_BATCH] -> restart the chain at [0] with that length
+        hint = remaining;
+        e = hipMemcpyAsync(cnt, cnt + NMS_BATCH, sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt + 1, 0, NMS_BATCH * sizeof(unsigned int), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(cnt + NMS_SNAP, cnt + NMS_SNAP + NMS_BATCH, sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return bail("sweep chain reset", e);
+    }
+    if (npicks > 0) {
+        if ((size_t)npicks > kcap) { prof_end(ctx); return done(fail(ctx, "nms: pick list overflow")); }
         size_t sp2 = 4096;
         while (sp2 < npicks) sp2 <<= 1;
         e = fill_u64(keys, npicks, sp2, 0ull, s);
@@ -2062,7 +2175,7 @@ static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, i
         const unsigned int nw = std::min<unsigned int>(npicks, (unsigned int)std::max(cap, 0));
         if (e == hipSuccess) e = nms_write(keys, nw, d_score, H, W, dims, d_coords, d_scores, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { prof_end(ctx); return done(fail(ctx, "nms: sort/write failed: %s", hipGetErrorString(e))); }
+        if (e != hipSuccess) return bail("sort/write", e);
     }
     prof_end(ctx);
     if (h_n) *h_n = (int)npicks;
@@ -2081,7 +2194,13 @@ int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float th
         while (hw * hw + dy * dy > r * r) --hw;
         halfw[dy + r] = hw;
     }
-    return nms_common(ctx, d_score, 1, H, W, 2, r, halfw.data(), (int)halfw.size(), threshold, d_coords, d_scores, cap, h_n);
+    // the disk's cells for the push kernel: dy * 65536 + (dx + 32768), appended after the half widths
+    const int n_hw = (int)halfw.size();
+    if (r > 16000) return fail(ctx, "tpz_nms_2d: radius too large");
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -halfw[dy + r]; dx <= halfw[dy + r]; ++dx) halfw.push_back(dy * 65536 + (dx + 32768));
+    return nms_common(ctx, d_score, 1, H, W, 2, r, halfw.data(), n_hw, (int)halfw.size() - n_hw, threshold, d_coords, d_scores,
+                      cap, h_n);
 }
 
 int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, float scale, float threshold,
@@ -2102,7 +2221,7 @@ int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, f
                 }
     std::sort(deltas.begin(), deltas.end());
     deltas.erase(std::unique(deltas.begin(), deltas.end()), deltas.end());
-    return nms_common(ctx, d_score, D, H, W, 3, r, deltas.data(), (int)deltas.size(), threshold, d_coords, d_scores, cap, h_n);
+    return nms_common(ctx, d_score, D, H, W, 3, r, deltas.data(), (int)deltas.size(), 0, threshold, d_coords, d_scores, cap, h_n);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------
