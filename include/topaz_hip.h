@@ -136,8 +136,11 @@ int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float th
                int32_t* d_coords, float* d_scores, int cap, int* h_n);
 /* replaces non_maximum_suppression_3d(x, r, scale, threshold) (topaz/algorithms.py:66-103):
  * flat-index deltas, no clipping (they wrap across rows/planes); d_coords [cap][3] (x, y, z). */
-int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, float scale,
+int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, double scale,
                float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n);
+/* (scale is a double: the reference forms r = scale * r in Python floats, and a lattice point at distance exactly r
+ *  must stay inside the ball -- 0.7f * 10 is 6.9999998, 0.7 * 10 is 7.0.  The threshold is compared with fp32 scores
+ *  as fp32, like numpy does for a float32 map.) */
 
 /* ---- single ops (unit tests and the host-side pipelines) --------------------------------- */
 /* one fused convolution: the op the layer program is made of.  h_w [cout][cin][k..], h_b [cout] or NULL.

@@ -128,3 +128,76 @@ def test_bench_weights_equal_test_weights():
         assert list(a) == list(b)
         for k in a:
             assert np.array_equal(a[k], b[k]), (arch, k)
+
+
+def test_unpickler_allowlist_refuses_foreign_globals(tmp_path):
+    """a model file is data: globals outside the allowlist (here os.system via __reduce__) raise UnpicklingError instead
+    of being called; the reference's own full-module pickles still load (tests/golden/user_model_*.sav)"""
+    import os
+    import pickle
+    import torch
+    from conftest import GOLDEN
+    from topaz_amd.model.unpickle import _PickleModule, load_module_pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('echo pwned > ' + str(tmp_path / 'pwned'),))
+
+    bad = tmp_path / 'evil.sav'
+    torch.save({'w': torch.zeros(2), 'x': Evil()}, str(bad))
+    with pytest.raises(pickle.UnpicklingError, match='system'):
+        torch.load(str(bad), map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    assert not (tmp_path / 'pwned').exists()
+    arch, sd = load_module_pickle(os.path.join(GOLDEN, 'user_model_resnet8_bn_u16.sav'))
+    assert arch == 'resnet8' and 'classifier.weight' in sd
+    arch, sd = load_module_pickle(os.path.join(GOLDEN, 'user_model_conv127_bn_u16.sav'))
+    assert arch == 'conv127'
+
+
+def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
+    """UDenoiseNet3 (--arch unet3) has UDenoiseNet's parameter names but returns x - dec1(h): it must be refused, not
+    evaluated as a UDenoiseNet.  The classes are faked under the reference's module path for pickling."""
+    import sys
+    import types
+    import torch
+    from tools import synth_weights as sw
+    from topaz_amd.denoising.models import _kind_from_class, load_model
+    from topaz_amd.model.unpickle import _PickleModule, _walk
+
+    fake = types.ModuleType('topaz.denoising.models')
+    pkgs = {n: types.ModuleType(n) for n in ('topaz', 'topaz.denoising')}
+
+    def make(name):
+        cls = type(name, (torch.nn.Module,), {'__module__': 'topaz.denoising.models'})
+        setattr(fake, name, cls)
+        return cls
+
+    sd = sw.unet_sd(3, nf=8, base_width=7, top_width=3)
+    saved = {}
+    try:
+        sys.modules.update(pkgs)
+        sys.modules['topaz.denoising.models'] = fake
+        for name in ('UDenoiseNet', 'UDenoiseNet3'):
+            m = make(name)()
+            for k, v in sd.items():
+                blk, idx, leaf = k.split('.')
+                if not hasattr(m, blk):
+                    setattr(m, blk, torch.nn.Sequential())
+                seq = getattr(m, blk)
+                while len(seq) <= int(idx):
+                    seq.append(torch.nn.Identity())
+                if not isinstance(seq[int(idx)], torch.nn.Conv2d):
+                    co, ci, kk = sd[f'{blk}.{idx}.weight'].shape[:3]
+                    seq[int(idx)] = torch.nn.Conv2d(ci, co, kk)
+                getattr(seq[int(idx)], leaf).data = torch.from_numpy(v)
+            saved[name] = str(tmp_path / (name + '.sav'))
+            torch.save(m, saved[name])
+    finally:
+        for n in list(pkgs) + ['topaz.denoising.models']:
+            sys.modules.pop(n, None)
+    obj = torch.load(saved['UDenoiseNet'], map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    got = {}
+    _walk(obj, '', got)
+    assert _kind_from_class(obj, got, 'x') == 'unet' and set(got) == set(sd)
+    with pytest.raises(NotImplementedError, match='UDenoiseNet3'):
+        load_model(saved['UDenoiseNet3'])

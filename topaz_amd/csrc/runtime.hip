@@ -2203,12 +2203,12 @@ int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float th
                       cap, h_n);
 }
 
-int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, float scale, float threshold,
+int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, double scale, float threshold,
                int32_t* d_coords, float* d_scores, int cap, int* h_n) {
     if (!ctx || !d_score || D < 1 || H < 1 || W < 1 || r < 0) return fail(ctx, "tpz_nms_3d: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // algorithms.py:68-79: r = scale*r (float), width = ceil(r), deltas over the ball
-    const double rr = (double)scale * (double)r;
+    const double rr = scale * (double)r;
     const int width = (int)std::ceil(rr);
     const long long zs = (long long)H * W, ys = W;
     std::vector<int> deltas;

@@ -120,7 +120,11 @@ def denoise_image(mic: np.ndarray, models: List[Denoise], lowpass=1, cutoff=0, g
         x = inv_gaus.apply(x)
     elif deconvolve:
         raise NotImplementedError('deconvolve: crashes in the reference (denoise.py:404 on ndarray input)')
-    out = sum(model.denoise(x, patch_size=patch_size, padding=padding) for model in models) / len(models)
+    if len(models) == 0:
+        # `-m none` (commands/denoise.py:100-106 still builds a Denoise around no model): the pre-filtered image passes through
+        out = np.asarray(x, dtype=np.float32)
+    else:
+        out = sum(model.denoise(x, patch_size=patch_size, padding=padding) for model in models) / len(models)
     if normalize:
         out = (out - out.mean()) / out.std()
     else:

@@ -124,8 +124,32 @@ def load_model(name, base_kernel_width: int = 11) -> DenoiseNet:
     from ..model.unpickle import _PickleModule, _walk
     obj = torch.load(fname, map_location='cpu', weights_only=False, pickle_module=_PickleModule)
     if isinstance(obj, (dict, OrderedDict)):
-        sd = obj
-    else:
-        sd = OrderedDict()
-        _walk(obj, '', sd)
-    return DenoiseNet(_kind_from_state_dict(sd), sd)
+        sd = obj                      # bare state_dict (how the reference saves 3-D models): the keys decide
+        return DenoiseNet(_kind_from_state_dict(sd), sd)
+    sd = OrderedDict()
+    _walk(obj, '', sd)
+    return DenoiseNet(_kind_from_class(obj, sd, fname), sd)
+
+
+# classes of topaz/denoising/models.py (and filters.AffineDenoise) this path evaluates -> kind.  The state_dict keys
+# alone do not identify the forward pass: UDenoiseNet3 (--arch unet3, models.py:339-449) has UDenoiseNet's keys but
+# returns x - dec1(h), UDenoiseNet2 / DenoiseNet differ in their layer lists.
+_CLASS_KIND = {
+    'UDenoiseNet': 'unet',
+    'UDenoiseNetSmall': 'unet-small',
+    'DenoiseNet2': 'fcnn',
+    'UDenoiseNet3D': 'unet-3d',
+    'AffineDenoise': 'affine',
+}
+
+
+def _kind_from_class(obj, sd, path) -> str:
+    qn = getattr(type(obj), '_tpz_qualname', '') or type(obj).__name__
+    cls = qn.rsplit('.', 1)[-1]
+    if cls not in _CLASS_KIND:
+        raise NotImplementedError(f'{path}: denoising model class {cls} is not supported on the MI355X path '
+                                  f'(supported: {", ".join(sorted(_CLASS_KIND))})')
+    kind = _kind_from_state_dict(sd)
+    if kind != _CLASS_KIND[cls]:
+        raise ValueError(f'{path}: a {cls} whose parameters look like a {kind!r} network')
+    return kind

@@ -82,7 +82,9 @@ class LinearClassifier:
 
     def cuda(self, device: Optional[int] = None):
         ctx = get_context(device)
-        if self._device_model is None or self._device != ctx.device:
+        # keyed by the context (device AND lane): a tpz_ctx's workspace pool and flags are not thread-safe, so two lane
+        # threads sharing one classifier must not end up on the same context
+        if self._device_model is None or self._device_model.ctx is not ctx:
             self._device_model = DeviceModel(self._program, ctx)
             self._device = ctx.device
         return self

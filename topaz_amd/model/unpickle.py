@@ -4,8 +4,10 @@ torch.load(weights_only=False)) WITHOUT importing the reference package.
 
 The pickle references topaz.model.classifier.LinearClassifier, topaz.model.features.resnet.{ResNet8,
 ResNet16,BasicConv,ResidA,MaxPool}, topaz.model.features.basic.{BasicConv,Conv127,...} and
-torch.nn.modules.* (SURVEY.md P10).  A restricted Unpickler maps every `topaz.*` global onto an
-inert stand-in class that just records its attribute dict; torch's own classes load normally.
+torch.nn.modules.* (SURVEY.md P10).  The Unpickler maps every `topaz.*` global onto an inert stand-in
+class that just records its attribute dict, lets through an explicit allowlist of torch / numpy /
+collections globals (tensor reconstruction, storages, torch.nn layer classes) and refuses everything
+else with UnpicklingError -- `torch.load(weights_only=False)` alone would execute arbitrary globals.
 The architecture is then recognised from the recorded class names and the state_dict is rebuilt
 by walking the `_modules` / `_parameters` / `_buffers` dictionaries.
 """
@@ -40,10 +42,43 @@ def _stub_for(module: str, name: str):
     return _stub_cache[key]
 
 
+# Globals a module pickle written by torch.save(model) legitimately needs (pickletools dump of the
+# reference's own files): tensor / parameter reconstruction, storages, dtypes, torch.nn layer classes, containers.
+# Everything else -- os.system, builtins.eval, subprocess ... -- is refused: a model file is data, not a program.
+_ALLOWED_EXACT = {
+    ('collections', 'OrderedDict'), ('builtins', 'set'), ('__builtin__', 'set'), ('builtins', 'frozenset'),
+    ('builtins', 'slice'), ('builtins', 'complex'), ('builtins', 'bytearray'),
+    ('torch._utils', '_rebuild_tensor'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'),
+    ('torch._utils', '_rebuild_parameter_with_state'), ('torch._utils', '_rebuild_qtensor'),
+    ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'),
+    ('torch.serialization', '_get_layout'), ('torch.nn.parameter', 'Parameter'), ('torch.nn.parameter', 'Buffer'),
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'ndarray'), ('numpy', 'dtype'),
+}
+_ALLOWED_TORCH_SUFFIX = ('Storage', 'Tensor')        # torch.FloatStorage, torch.LongStorage, torch.FloatTensor, ...
+_TORCH_DTYPES = {'float16', 'float32', 'float64', 'bfloat16', 'int8', 'int16', 'int32', 'int64', 'uint8', 'bool'}
+
+
+def _allowed(module: str, name: str) -> bool:
+    if (module, name) in _ALLOWED_EXACT:
+        return True
+    if module == 'torch' and (name.endswith(_ALLOWED_TORCH_SUFFIX) or name in _TORCH_DTYPES):
+        return True
+    if module == 'torch.storage' and name in ('UntypedStorage', 'TypedStorage', '_load_from_bytes'):
+        return True
+    # layer classes: plain attribute containers, instantiated via __reduce__ / __setstate__ only
+    if module.startswith('torch.nn.modules.') and name[:1].isupper() and name.isidentifier():
+        return True
+    return False
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == 'topaz' or module.startswith('topaz.'):
             return _stub_for(module, name)
+        if not _allowed(module, name):
+            raise pickle.UnpicklingError(f'model file refers to {module}.{name}, which a topaz model pickle has no '
+                                         f'business loading (allowlist: topaz_amd/model/unpickle.py)')
         return super().find_class(module, name)
 
 
