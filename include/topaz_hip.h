@@ -142,6 +142,35 @@ int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, d
  *  must stay inside the ball -- 0.7f * 10 is 6.9999998, 0.7 * 10 is 7.0.  The threshold is compared with fp32 scores
  *  as fp32, like numpy does for a float32 map.) */
 
+/* ---- host buffers: staging ring and host-pointer entry points ----------------------------------------------
+ * The reference's callers own numpy images (extract.py:234-251 loads one, scores it, hands the map on; denoise.py:463-488
+ * likewise).  A tpz_stage is a ring of `depth` slots -- pinned host buffer + device buffer + events -- with its own copy
+ * stream: the H2D copy of image i+1 and the D2H copy of result i-1 run under the kernels of image i.
+ *   producer:  p = tpz_stage_host_ptr(st, k);  fill p (e.g. read the file into it);  tpz_stage_h2d(st, k, NULL, bytes)
+ *              (or tpz_stage_h2d(st, k, h_src, bytes): h_src is first copied into the pinned buffer)
+ *   consumer:  tpz_stage_acquire(st, k)  -- the ctx stream waits for the copy (no host wait);
+ *              ... kernels reading tpz_stage_device_ptr(st, k) ...;  tpz_stage_release(st, k)
+ *   results:   tpz_stage_d2h(st, k, d_src, bytes) queues device -> pinned slot k after the work already on the ctx stream;
+ *              tpz_stage_wait(st, k) blocks the host until slot k's last copy has finished.
+ * A slot is reused only after the kernels that read it were released (h2d waits for the release event). */
+typedef struct tpz_stage tpz_stage;
+int tpz_stage_create(tpz_ctx* ctx, size_t slot_bytes, int depth, tpz_stage** out);
+void tpz_stage_free(tpz_stage* st);
+void* tpz_stage_host_ptr(tpz_stage* st, int slot);
+void* tpz_stage_device_ptr(tpz_stage* st, int slot);
+int tpz_stage_h2d(tpz_stage* st, int slot, const void* h_src, size_t bytes);
+int tpz_stage_acquire(tpz_stage* st, int slot);
+int tpz_stage_release(tpz_stage* st, int slot);
+int tpz_stage_d2h(tpz_stage* st, int slot, const void* d_src, size_t bytes);
+int tpz_stage_wait(tpz_stage* st, int slot);
+/* Host-pointer forms of the three calls of the path (synchronous; plain pageable or pinned memory), the signatures
+ * SURVEY.md 8(b) sketches: model(x) on a numpy image (extract.py:247-249), Denoise.denoise (denoise.py:327-332),
+ * non_maximum_suppression (algorithms.py:25-63).  Each stages through an internal ring owned by the ctx. */
+int tpz_score_2d_host(tpz_model* m, const float* h_in, int H, int W, float* h_out_logits);
+int tpz_denoise_2d_host(tpz_model* m, const float* h_in, int H, int W, int patch, int pad, float* h_out);
+int tpz_nms_2d_host(tpz_ctx* ctx, const float* h_score, int H, int W, int r, float threshold, int32_t* h_coords,
+                    float* h_scores, int cap, int* h_n);
+
 /* ---- single ops (unit tests and the host-side pipelines) --------------------------------- */
 /* one fused convolution: the op the layer program is made of.  h_w [cout][cin][k..], h_b [cout] or NULL.
  * d_in2 / d_res / h_post_* may be NULL.  in is [cin1][D1][H1][W1]; when d_in2 != NULL it is

@@ -284,6 +284,125 @@ def cli():
         print('cli/' + fn, os.path.getsize(os.path.join(cli_dir, fn)))
 
 
+def scoring3d():
+    """3-D scoring (`--dims 3`): LinearClassifier(ResNet8(dims=3)) seeded, filled, on small tomograms, and
+    classify_patches (classifier.py:69-102) over PatchDataset tiles; plus non_maximum_suppression_3d of the map."""
+    from topaz.algorithms import non_maximum_suppression_3d
+    from topaz.model.classifier import LinearClassifier, classify_patches
+    from topaz.model.features.resnet import ResNet8, ResNet16
+    rs = np.random.RandomState(91)
+    for name, ctor, units, bn, shape in (('resnet8_3d_u8', ResNet8, 8, False, (20, 26, 30)),
+                                         ('resnet8_3d_bn_u8', ResNet8, 8, True, (18, 20, 24)),
+                                         ('resnet16_3d_u8', ResNet16, 8, False, (14, 18, 20))):
+        torch.manual_seed(92 + len(name))
+        m = LinearClassifier(ctor(dims=3, units=units, bn=bn), dims=3)
+        if bn:
+            randomise_bn(m, 93)
+        m.eval()
+        m.fill()
+        x = rs.randn(*shape).astype(np.float32)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x)[None, None])[0, 0].numpy()
+        arrays = dict(arch=np.asarray(name.split('_')[0]), x0=x, y0=y, **sd_arrays(m))
+        if name == 'resnet8_3d_u8':
+            s, c = non_maximum_suppression_3d(y, 3, threshold=float(np.quantile(y, 0.5)))
+            arrays.update(nms_r=np.asarray(3), nms_thr=np.asarray(np.float32(np.quantile(y, 0.5))), nms_scores=s, nms_coords=c)
+            with torch.no_grad():
+                yp = classify_patches(m, torch.from_numpy(x)[None], patch_size=16, padding=35, batch_size=2, verbose=False)
+            arrays.update(patched=yp[0].numpy(), patch_size=np.asarray(16), padding=np.asarray(35))
+            torch.save(m, os.path.join(OUT, 'user_model_resnet8_3d_u8.sav'))
+        save('score_' + name, **arrays)
+
+
+def extras():
+    """rows the first round left partial: the radius search / validation of `topaz extract --targets`
+    (extract.py:135-204,284-305), `topaz segment` score maps (model/utils.py:71-105), the inverse-Gaussian pre-filter.
+    InvGaussianFilter itself cannot be constructed upstream (filters.py:85 calls GaussianDenoise.__init__ without
+    sigma -> TypeError), so its golden is assembled from the reference's working parts: gaussian_filter,
+    inverse_filter and AffineFilter (filters.py:6-38)."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import pandas as pd
+    from topaz import mrc
+    import topaz.commands.extract as cmd_extract
+    from topaz.filters import AffineFilter, gaussian_filter, inverse_filter
+    from topaz.model.factory import load_model
+    from topaz.model.utils import segment_images
+    cli_dir = os.path.join(OUT, 'cli')
+    tmp = tempfile.mkdtemp()
+    try:
+        mics = []
+        for name in ('mic_a', 'mic_b'):
+            shutil.copy(os.path.join(cli_dir, name + '.mrc'), os.path.join(tmp, name + '.mrc'))
+            mics.append(os.path.join(tmp, name + '.mrc'))
+        # targets: a subset of the reference's own r = 8 picks, jittered by up to 2 px, plus a few decoys
+        picks = pd.read_csv(os.path.join(cli_dir, 'extract_picks.txt'), sep='\t')
+        rs = np.random.RandomState(77)
+        keep = picks[picks.score > -3.5].copy()
+        keep = keep.iloc[rs.permutation(len(keep))[: max(20, len(keep) // 2)]]
+        keep['x_coord'] = np.clip(keep.x_coord + rs.randint(-2, 3, len(keep)), 0, 199)
+        keep['y_coord'] = np.clip(keep.y_coord + rs.randint(-2, 3, len(keep)), 0, 159)
+        decoys = pd.DataFrame({'image_name': ['mic_a'] * 5 + ['mic_b'] * 5, 'x_coord': rs.randint(0, 200, 10),
+                               'y_coord': rs.randint(0, 160, 10), 'score': 0.0})
+        targets = pd.concat([keep, decoys])[['image_name', 'x_coord', 'y_coord']]
+        # the reference keys its score dict by the PATH it was given and looks the targets' image_name up in it
+        # (extract.py:284-290): they only meet when the table names the micrographs exactly as the command line does
+        targets['image_name'] = targets['image_name'] + '.mrc'
+
+        tpath = os.path.join(cli_dir, 'targets.txt')
+        targets.to_csv(tpath, sep='\t', index=False)
+
+        def run(argv):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                cmd_extract.main(cmd_extract.add_arguments().parse_args(argv))
+            return buf.getvalue()
+
+        # (a) radius search: no -r, --targets given -> find_opt_radius over 4..16 step 4, then extraction at the optimum
+        # (run from inside the directory so that the paths are the bare file names the targets table uses)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            out = run(['-m', 'resnet8_u32', '-d', '-1', '--targets', tpath, '--min-radius', '4', '--max-radius', '16',
+                       '--step-radius', '4', '-o', os.path.join(tmp, 'opt_picks.txt'), 'mic_a.mrc', 'mic_b.mrc'])
+            with open(os.path.join(cli_dir, 'targets_search_stdout.txt'), 'w') as f:
+                f.write(out)
+            shutil.copy(os.path.join(tmp, 'opt_picks.txt'), os.path.join(cli_dir, 'targets_search_picks.txt'))
+            # (b) validation at a fixed radius with an assignment radius
+            out = run(['-m', 'resnet8_u32', '-d', '-1', '-r', '8', '--assignment-radius', '5', '--targets', tpath,
+                       '--only-validate', 'mic_a.mrc', 'mic_b.mrc'])
+            with open(os.path.join(cli_dir, 'targets_validate_stdout.txt'), 'w') as f:
+                f.write(out)
+        finally:
+            os.chdir(cwd)
+        # (c) topaz segment: the score map of mic_a as the float32 TIFF the reference writes
+        m = load_model('resnet8_u32')
+        m.eval()
+        m.fill()
+        segment_images(m, mics[:1], os.path.join(tmp, 'seg'), use_cuda=False, verbose=False)
+        shutil.copy(os.path.join(tmp, 'seg', 'mic_a.tiff'), os.path.join(cli_dir, 'segment_mic_a.tiff'))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # (d) inverse Gaussian filter from the reference's working parts
+    x = image(95, 90, 120) * 3 + 10
+    out = {'x': x}
+    for sigma in (0.8, 1.5):
+        width = 1 + 2 * int(np.ceil(sigma * 5))
+        f = gaussian_filter(sigma, s=width)
+        f /= f.sum()
+        Fi = inverse_filter(f)
+        with torch.no_grad():
+            y = AffineFilter(Fi)(torch.from_numpy(x)[None, None])[0, 0].numpy()
+        out[f'kernel:{sigma}'] = Fi
+        out[f'y:{sigma}'] = y
+    save('inv_gaussian', **out)
+    for fn in ('targets.txt', 'targets_search_stdout.txt', 'targets_search_picks.txt', 'targets_validate_stdout.txt',
+               'segment_mic_a.tiff'):
+        print('cli/' + fn, os.path.getsize(os.path.join(cli_dir, fn)))
+
+
 def downsample():
     """truncated-DFT downsample (utils/image.py:38-61), the step before the path in `topaz preprocess`"""
     from topaz.utils.image import downsample as ref_downsample

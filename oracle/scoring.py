@@ -76,32 +76,34 @@ def _bn(y, sd, prefix):
 
 def resnet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: List[dict], prefix='features.features.',
                    head=True) -> torch.Tensor:
-    """Filled forward of LinearClassifier(ResNetN): x [N,1,H,W] -> logits [N,1,H,W].
+    """Filled forward of LinearClassifier(ResNetN): x [N,1,(D,)H,W] -> logits [N,1,(D,)H,W].
     resnet.py:243-251 (pad by width//2, Sequential), :101-105 (BasicConv), :185-202 (ResidA),
     classifier.py:64-66 (1x1 head)."""
+    dims = x.dim() - 2                         # 2-D micrographs or 3-D tomograms (resnet.py:56-63,115-123,186-197)
+    conv = F.conv3d if dims == 3 else F.conv2d
     p = width_of(spec) // 2
-    h = F.pad(x, (p, p, p, p))
+    h = F.pad(x, (p, p) * dims)
     for i, m in enumerate(spec):
         pre = f'{prefix}{i}.'
         if m['type'] == 'basic':
-            h = F.conv2d(h, sd[pre + 'conv.weight'], sd.get(pre + 'conv.bias'), dilation=m['conv_dil'])
+            h = conv(h, sd[pre + 'conv.weight'], sd.get(pre + 'conv.bias'), dilation=m['conv_dil'])
             h = _bn(h, sd, pre + 'bn')
             h = F.relu(h)
         else:
             d0, d1 = m['conv0_fdil'], m['conv1_fdil']
-            t = F.conv2d(h, sd[pre + 'conv0.weight'], sd.get(pre + 'conv0.bias'), dilation=d0)
+            t = conv(h, sd[pre + 'conv0.weight'], sd.get(pre + 'conv0.bias'), dilation=d0)
             t = _bn(t, sd, pre + 'bn0')
             t = F.relu(t)
-            y = F.conv2d(t, sd[pre + 'conv1.weight'], sd.get(pre + 'conv1.bias'), dilation=d1)
+            y = conv(t, sd[pre + 'conv1.weight'], sd.get(pre + 'conv1.bias'), dilation=d1)
             edge = d0 + d1
-            xs = h[:, :, edge:-edge, edge:-edge]
+            xs = h[(slice(None), slice(None)) + (slice(edge, -edge),) * dims]
             if pre + 'proj.weight' in sd:
-                xs = F.conv2d(xs, sd[pre + 'proj.weight'])
+                xs = conv(xs, sd[pre + 'proj.weight'])
             y = y + xs
             y = _bn(y, sd, pre + 'bn1')      # bn1 comes AFTER the add (resnet.py:199-201)
             h = F.relu(y)
     if head:
-        h = F.conv2d(h, sd['classifier.weight'], sd['classifier.bias'])
+        h = conv(h, sd['classifier.weight'], sd['classifier.bias'])
     return h
 
 
@@ -143,7 +145,8 @@ def to_torch_sd(sd) -> Dict[str, torch.Tensor]:
 
 @torch.no_grad()
 def score(arch: str, sd, x: np.ndarray, num_threads: int = 0) -> np.ndarray:
-    """logits of one [H,W] image with the filled network `arch` (what extract.py:247-249 computes)."""
+    """logits of one [H,W] image (or [D,H,W] tomogram, with 3-D weights) with the filled network `arch` (what
+    extract.py:247-249 computes)."""
     if num_threads:
         torch.set_num_threads(num_threads)
     sd = to_torch_sd(sd)

@@ -76,7 +76,79 @@ def test_segment_tiff(gpu_ctx, tmp_path):
     _run(['segment', '-m', 'resnet8_u32', '-o', str(tmp_path / 'seg'), str(tmp_path / 'mic_a.mrc')])
     y = np.array(Image.open(tmp_path / 'seg' / 'mic_a.tiff'))
     assert y.shape == (160, 200) and y.dtype == np.float32
-    # consistency with the pick file of the reference: the top pick of mic_a is the arg-max of the map
-    ref = pd.read_csv(os.path.join(CLI, 'extract_picks.txt'), sep='\t')
-    top = ref[ref.image_name == 'mic_a'].iloc[0]
-    assert abs(y[top.y_coord, top.x_coord] - top.score) <= 1e-4
+    # the whole map against the TIFF the reference's segment_images wrote for this micrograph
+    ref = np.array(Image.open(os.path.join(CLI, 'segment_mic_a.tiff')))
+    assert ref.shape == y.shape and np.abs(y - ref).max() <= 1e-4
+    # patched mode (`-p`): upstream crashes on an unsupported keyword; the evident intent is tiles of
+    # 2 * patch_size with width // 2 halo, whose stitched map equals the whole-image one
+    _run(['segment', '-m', 'resnet8_u32', '-p', '48', '-o', str(tmp_path / 'segp'), str(tmp_path / 'mic_a.mrc')])
+    yp = np.array(Image.open(tmp_path / 'segp' / 'mic_a.tiff'))
+    assert np.abs(yp - ref).max() <= 1e-4
+
+
+def _capture(argv):
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        _run(argv)
+    return buf.getvalue()
+
+
+def _radius_lines(text):
+    rows = []
+    for line in text.strip().split('\n'):
+        if line.startswith('# radius='):
+            rows.append({k: float(v) for k, v in (kv.split('=') for kv in line[2:].split(', '))})
+    return rows
+
+
+def test_extract_targets_radius_search_and_validation(gpu_ctx, tmp_path, monkeypatch):
+    """`topaz extract --targets`: the radius search (no -r) prints one line per radius and extracts at the optimum; with -r it
+    prints the validation line.  Compared with the stdout and the pick file of the reference's own CLI on the same
+    micrographs and targets table (oracle/make_golden.py extras): same radii, same recall / target counts, AUPRC and RMSE
+    to 1e-6, the same pick table."""
+    for n in ('mic_a.mrc', 'mic_b.mrc'):
+        shutil.copy(os.path.join(CLI, n), tmp_path / n)
+    monkeypatch.chdir(tmp_path)                      # the targets table names the micrographs as the command line does
+    out = tmp_path / 'opt.txt'
+    text = _capture(['extract', '-m', 'resnet8_u32', '-d', '0', '--targets', os.path.join(CLI, 'targets.txt'), '--min-radius', '4',
+                     '--max-radius', '16', '--step-radius', '4', '-o', str(out), 'mic_a.mrc', 'mic_b.mrc'])
+    got, ref = _radius_lines(text), _radius_lines(open(os.path.join(CLI, 'targets_search_stdout.txt')).read())
+    assert [g['radius'] for g in got] == [4, 8, 12, 16] and len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert (g['radius'], g['recall'], g['targets']) == (r['radius'], r['recall'], r['targets'])
+        assert abs(g['auprc'] - r['auprc']) <= 1e-6 and abs(g['rmse'] - r['rmse']) <= 1e-6
+    a, b = pd.read_csv(out, sep='\t'), pd.read_csv(os.path.join(CLI, 'targets_search_picks.txt'), sep='\t')
+    assert a.image_name.tolist() == b.image_name.tolist()
+    assert np.array_equal(a[['x_coord', 'y_coord']].values, b[['x_coord', 'y_coord']].values)
+    assert np.abs(a.score.values - b.score.values).max() <= 1e-4
+    text = _capture(['extract', '-m', 'resnet8_u32', '-d', '0', '-r', '8', '--assignment-radius', '5', '--targets',
+                     os.path.join(CLI, 'targets.txt'), '--only-validate', 'mic_a.mrc', 'mic_b.mrc'])
+    (g,), (r,) = _radius_lines(text), _radius_lines(open(os.path.join(CLI, 'targets_validate_stdout.txt')).read())
+    assert (g['radius'], g['recall'], g['targets']) == (r['radius'], r['recall'], r['targets'])
+    assert abs(g['auprc'] - r['auprc']) <= 1e-6 and abs(g['rmse'] - r['rmse']) <= 1e-6
+
+
+def test_extract_tomogram_dims3(gpu_ctx, tmp_path):
+    """`topaz extract --dims 3`: a 3-D classifier pickle scores a tomogram read from an MRC file and the 3-D suppression writes
+    x, y, z columns; the table equals the reference's non_maximum_suppression_3d of the reference's own score map wherever
+    the device map agrees with it (the golden's threshold sits at the median of a dense map: ties within 1e-4 may flip)"""
+    from conftest import load_golden
+    from topaz_amd import mrc
+    z = load_golden('score_resnet8_3d_u8')
+    with open(tmp_path / 'tomo.mrc', 'wb') as f:
+        mrc.write(f, z['x0'])
+    out = tmp_path / 'picks3d.txt'
+    _run(['extract', '-m', os.path.join(GOLDEN, 'user_model_resnet8_3d_u8.sav'), '--dims', '3', '-r', str(int(z['nms_r'])), '-t',
+          repr(float(z['nms_thr'])), '-d', '0', '-o', str(out), str(tmp_path / 'tomo.mrc')])
+    t = pd.read_csv(out, sep='\t')
+    assert list(t.columns) == ['image_name', 'x_coord', 'y_coord', 'z_coord', 'score']
+    ref_c, ref_s = z['nms_coords'], z['nms_scores']
+    got = {tuple(r) for r in t[['x_coord', 'y_coord', 'z_coord']].values.tolist()}
+    want = {tuple(r) for r in ref_c.tolist()}
+    assert len(got ^ want) <= max(2, len(want) // 50), (len(got), len(want), len(got ^ want))
+    common = sorted(got & want)
+    lookup = {tuple(c): s for c, s in zip(ref_c.tolist(), ref_s.tolist())}
+    mine = {tuple(r[:3]): r[3] for r in t[['x_coord', 'y_coord', 'z_coord', 'score']].values.tolist()}
+    assert max(abs(mine[tuple(map(float, c))] - lookup[c]) for c in common) <= 1e-4

@@ -128,3 +128,28 @@ def test_nan_scores_sort_first(gpu_ctx):
     assert np.array_equal(c, co)
     assert np.array_equal(np.isnan(s), np.isnan(so)) and np.array_equal(s[~np.isnan(s)], so[~np.isnan(so)])
     assert np.isnan(s[:3]).all() and set(map(tuple, c[:3].tolist())) == {(7, 5), (30, 20), (10, 30)}
+
+
+def test_patched_suppression_matches_whole_image_on_separated_peaks(gpu_ctx):
+    """NonMaximumSuppression with tiles (the branch that cannot run upstream, extract.py:42-72): peaks further apart than
+    the suppression radius and an overlap >= radius make tile-wise and whole-image suppression agree, borders included
+    (2-D and 3-D)"""
+    from topaz_amd.extract import NonMaximumSuppression
+    rs = np.random.RandomState(9)
+    x = np.full((150, 170), -10.0, dtype=np.float32)
+    ys, xs = np.meshgrid(np.arange(3, 150, 12), np.arange(2, 170, 12), indexing='ij')
+    x[ys, xs] = rs.rand(*ys.shape).astype(np.float32) + 1
+    whole = NonMaximumSuppression(5, -6.0, patch_size=0)(('a', x))
+    tiled = NonMaximumSuppression(5, -6.0, patch_size=64, patch_overlap=8)(('a', x))
+    assert len(whole[1]) == ys.size
+    assert sorted(map(tuple, whole[2].tolist())) == sorted(map(tuple, tiled[2].tolist()))
+    assert sorted(whole[1].tolist()) == sorted(tiled[1].tolist())
+    v = np.full((40, 44, 48), -10.0, dtype=np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(2, 40, 9), np.arange(3, 44, 9), np.arange(1, 48, 9), indexing='ij')
+    v[zz, yy, xx] = rs.rand(*zz.shape).astype(np.float32) + 1
+    whole = NonMaximumSuppression(3, -6.0, dims=3, patch_size=0)(('v', v))
+    tiled = NonMaximumSuppression(3, -6.0, dims=3, patch_size=24, patch_overlap=4)(('v', v))
+    assert len(whole[1]) == zz.size
+    assert sorted(map(tuple, whole[2].tolist())) == sorted(map(tuple, tiled[2].tolist()))
+    with pytest.raises(ValueError, match='no core'):
+        NonMaximumSuppression(5, -6.0)(('a', x))           # the upstream default 64 / 32 has step 0

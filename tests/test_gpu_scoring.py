@@ -139,14 +139,60 @@ def test_edge_tiny_and_ragged_images(gpu_ctx):
         assert np.abs(y - oscoring.score('resnet8', sd, x)).max() <= ATOL, shape
 
 
-def test_batched_scoring_matches_single(gpu_ctx):
-    """topaz.predict.score semantics: a batch is scored image by image (predict.py:18-28)"""
+def test_batched_scoring_vs_oracle(gpu_ctx):
+    """topaz.predict.batches / score_stream / score (predict.py:7-35): images are stacked batch_size at a time, the
+    batch goes through model(x.unsqueeze(1)), one array per image comes back -- each must equal the ORACLE's logits
+    of that image (a ragged last batch included), and a batch must not depend on its neighbours"""
     from topaz_amd.model.factory import load_model
-    from topaz_amd.predict import score
+    from topaz_amd.predict import batches, score, score_stream
     m = load_model('resnet16_u32')
     m.eval(); m.fill(); m.cuda()
-    imgs = [np.random.RandomState(s).randn(64, 80).astype(np.float32) for s in (1, 2, 3)]
-    out = score(m, imgs, batch_size=2)
-    assert len(out) == 3
-    for x, y in zip(imgs, out):
-        assert np.array_equal(y, m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy())
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    imgs = [np.random.RandomState(s).randn(64, 80).astype(np.float32) for s in (1, 2, 3, 4, 5)]
+    refs = [oscoring.score('resnet16', sd, x) for x in imgs]
+    assert [tuple(b.shape) for b in batches(imgs, batch_size=2)] == [(2, 64, 80), (2, 64, 80), (1, 64, 80)]
+    for bs in (1, 2, 5):
+        out = score(m, imgs, use_cuda=True, batch_size=bs)
+        assert len(out) == 5
+        for y, ref in zip(out, refs):
+            assert y.shape == ref.shape and np.abs(y - ref).max() <= ATOL
+    streamed = list(score_stream(m, iter(imgs), use_cuda=True, batch_size=3))
+    for y, y1 in zip(streamed, score(m, imgs, use_cuda=True, batch_size=1)):
+        assert np.array_equal(y, y1)
+
+
+# ---- 3-D scoring (`--dims 3`): filled ResNet8 / ResNet16 over Conv3d weights, classify_patches, NMS-3D -------------------
+@pytest.mark.parametrize('name', ['resnet8_3d_u8', 'resnet8_3d_bn_u8', 'resnet16_3d_u8'])
+def test_scoring_3d_vs_reference_golden(gpu_ctx, name):
+    from topaz_amd.model.classifier import LinearClassifier
+    z = load_golden(f'score_{name}')
+    m = LinearClassifier(str(z['arch']), golden_sd(z))
+    assert m.dims == 3 and m.width == {'resnet8': 71, 'resnet16': 91}[str(z['arch'])]
+    m.eval(); m.fill(); m.cuda()
+    x = z['x0']
+    y = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
+    assert y.shape == x.shape
+    assert np.abs(y - z['y0']).max() <= ATOL
+    assert np.abs(y - oscoring.score(str(z['arch']), golden_sd(z), x)).max() <= ATOL
+
+
+def test_scoring_3d_patches_nms_and_user_pickle(gpu_ctx):
+    """classify_patches (PatchDataset tiles, zero-filled halo) vs the reference's output; the 3-D pick table of the
+    reference's own score map; a full-module pickle of a 3-D classifier loads and scores like the reference did"""
+    import os
+    from conftest import GOLDEN
+    from topaz_amd.algorithms import non_maximum_suppression_3d
+    from topaz_amd.model.classifier import classify_patches
+    from topaz_amd.model.factory import load_model
+    z = load_golden('score_resnet8_3d_u8')
+    m = load_model(os.path.join(GOLDEN, 'user_model_resnet8_3d_u8.sav'))
+    assert m.dims == 3
+    m.eval(); m.fill(); m.cuda()
+    x = z['x0']
+    y = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
+    assert np.abs(y - z['y0']).max() <= ATOL
+    yp = classify_patches(m, torch.from_numpy(x)[None], patch_size=int(z['patch_size']), padding=int(z['padding']),
+                          verbose=False)[0].numpy()
+    assert np.abs(yp - z['patched']).max() <= ATOL
+    s, c = non_maximum_suppression_3d(z['y0'], int(z['nms_r']), threshold=float(z['nms_thr']))
+    assert np.array_equal(c, z['nms_coords']) and np.array_equal(s, z['nms_scores'])

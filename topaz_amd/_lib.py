@@ -55,6 +55,18 @@ _SIGNATURES = {
     'tpz_nms_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     'tpz_nms_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, _P, _P, C.c_int,
                              C.POINTER(C.c_int)]),
+    'tpz_stage_create': (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(_P)]),
+    'tpz_stage_free': (None, [_P]),
+    'tpz_stage_host_ptr': (_P, [_P, C.c_int]),
+    'tpz_stage_device_ptr': (_P, [_P, C.c_int]),
+    'tpz_stage_h2d': (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    'tpz_stage_acquire': (C.c_int, [_P, C.c_int]),
+    'tpz_stage_release': (C.c_int, [_P, C.c_int]),
+    'tpz_stage_d2h': (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    'tpz_stage_wait': (C.c_int, [_P, C.c_int]),
+    'tpz_score_2d_host': (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    'tpz_denoise_2d_host': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'tpz_nms_2d_host': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     'tpz_conv': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                            C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, _P, _P, _P,
                            C.c_float, _P]),

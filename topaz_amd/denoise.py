@@ -132,103 +132,155 @@ def denoise_image(mic: np.ndarray, models: List[Denoise], lowpass=1, cutoff=0, g
     return out
 
 
-# ---- file-level drivers (denoise.py:419-557) ----------------------------------------------------------
+# ---- file-level drivers -----------------------------------------------------------------------------------------------
+# Counterparts of denoise_stack (denoise.py:419-447), denoise_stream (:450-490), denoise_tomogram (:495-530) and
+# denoise_tomogram_stream (:533-557): same arguments, same files on disk.  Structure here: a Job names one input and its
+# output path; `_run_jobs` overlaps the disk read of job i+1 and the write of job i-1 with the GPU work of job i (one
+# reader and one writer thread around the device loop) and shards the jobs over the ranks when launched multi-process.
+class _Job:
+    __slots__ = ('index', 'src', 'dst')
+
+    def __init__(self, index: int, src: str, dst: str):
+        self.index, self.src, self.dst = index, src, dst
+
+
+def _output_path(src: str, outdir: Optional[str], suffix: str, ext: str) -> str:
+    """<outdir>/<name><suffix><ext>, or next to the input with '.denoised' when no directory is given
+    (denoise.py:476-483, 512-520)"""
+    stem, _ = os.path.splitext(src)
+    if not outdir:
+        return stem + (suffix or '.denoised') + ext
+    return os.path.join(outdir, os.path.basename(stem) + suffix + ext)
+
+
+def _run_jobs(jobs: List[_Job], read, process, write, progress) -> list:
+    """read(job) -> item; process(job, item) -> result; write(job, item, result).  Reads run one job ahead and writes one
+    job behind the processing, each on its own thread; exceptions of either surface here."""
+    from concurrent.futures import ThreadPoolExecutor
+    results = []
+    if not jobs:
+        return results
+    with ThreadPoolExecutor(1, 'tpz-read') as reader, ThreadPoolExecutor(1, 'tpz-write') as writer:
+        nxt = reader.submit(read, jobs[0])
+        pending = None
+        for n, job in enumerate(jobs):
+            item = nxt.result()
+            if n + 1 < len(jobs):
+                nxt = reader.submit(read, jobs[n + 1])
+            result = process(job, item)
+            if pending is not None:
+                pending.result()
+            pending = writer.submit(write, job, item, result)
+            results.append(result)
+            progress(n + 1)
+        if pending is not None:
+            pending.result()
+    return results
+
+
 def denoise_stack(path: str, output_path: str, models: List[Denoise], lowpass: float = 1, pixel_cutoff: float = 0,
                   gaus=None, inv_gaus=None, deconvolve: bool = True, deconv_patch: int = 1, patch_size: int = 1024,
                   padding: int = 500, normalize: bool = True, use_cuda: bool = True):
+    """every section of one MRC stack, written back as one stack with the input's header"""
     from . import mrc
     with open(path, 'rb') as f:
-        content = f.read()
-    stack, header, extended_header = mrc.parse(content)
+        stack, header, extended_header = mrc.parse(f.read())
     print('# denoising stack with shape:', stack.shape, file=sys.stderr)
-    denoised = np.zeros_like(stack)
-    for i in range(len(stack)):
-        denoised[i] = denoise_image(stack[i], models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
-                                    deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size,
-                                    padding=padding, normalize=normalize, use_cuda=use_cuda)
-        print('# {} of {} completed.'.format(i + 1, len(stack)), file=sys.stderr, end='\r')
+    out = np.zeros_like(stack)
+    for k, section in enumerate(stack):
+        out[k] = denoise_image(section, models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
+                               deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size, padding=padding,
+                               normalize=normalize, use_cuda=use_cuda)
+        print(f'# {k + 1} of {len(stack)} completed.', file=sys.stderr, end='\r')
     print('', file=sys.stderr)
     print('# writing to', output_path, file=sys.stderr)
     with open(output_path, 'wb') as f:
-        mrc.write(f, denoised, header=header, extended_header=extended_header)
-    return denoised
+        mrc.write(f, out, header=header, extended_header=extended_header)
+    return out
 
 
 def denoise_stream(micrographs: List[str], output_path: str, format: str = 'mrc', suffix: str = '',
                    models: List[Denoise] = None, lowpass: float = 1, pixel_cutoff: float = 0, gaus=None, inv_gaus=None,
                    deconvolve: bool = True, deconv_patch: int = 1, patch_size: int = 1024, padding: int = 500,
                    normalize: bool = True, use_cuda: bool = True):
-    """With WORLD_SIZE > 1 (torchrun) rank r denoises micrographs r, r+world, ... and writes its own files."""
+    """one output image per micrograph; rank r of a multi-process launch takes micrographs r, r + world, ..."""
     from . import parallel
     from .utils.image import load_image, save_image
     rank, _, world = parallel.init_from_env()
-    total = len(micrographs)
-    denoised = []
-    if output_path is not None and output_path != '':
+    if output_path:
         os.makedirs(output_path, exist_ok=True)
-    for count, idx in enumerate(parallel.shard_indices(total, rank, world)):
-        path = micrographs[idx]
-        name, _ = os.path.splitext(os.path.basename(path))
-        image = load_image(path, make_image=False)
-        image, header, extended_header = image if type(image) is tuple else (image, None, None)
-        mic = denoise_image(image, models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
-                            deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size, padding=padding,
-                            normalize=normalize, use_cuda=use_cuda)
-        denoised.append(mic)
-        if not output_path:
-            if suffix == '' or suffix is None:
-                suffix = '.denoised'
-            no_ext, ext = os.path.splitext(path)
-            outpath = no_ext + suffix + '.' + format
-        else:
-            outpath = output_path + os.sep + name + suffix + '.' + format
-        save_image(mic, outpath, header=header, extended_header=extended_header)
-        print(f'# {count + 1} of {total} completed.', file=sys.stderr, end='\r')
+    jobs = [_Job(i, micrographs[i], _output_path(micrographs[i], output_path, suffix, '.' + format))
+            for i in parallel.shard_indices(len(micrographs), rank, world)]
+
+    def read(job):
+        loaded = load_image(job.src, make_image=False)
+        return loaded if isinstance(loaded, tuple) else (loaded, None, None)
+
+    def process(job, item):
+        return denoise_image(item[0], models, lowpass=lowpass, cutoff=pixel_cutoff, gaus=gaus, inv_gaus=inv_gaus,
+                             deconvolve=deconvolve, deconv_patch=deconv_patch, patch_size=patch_size, padding=padding,
+                             normalize=normalize, use_cuda=use_cuda)
+
+    def write(job, item, mic):
+        save_image(mic, job.dst, header=item[1], extended_header=item[2])
+
+    total = len(micrographs)
+    out = _run_jobs(jobs, read, process, write, lambda n: print(f'# {n} of {total} completed.', file=sys.stderr, end='\r'))
     print('', file=sys.stderr)
-    return denoised
+    return out
+
+
+def _tomogram_io():
+    from . import mrc
+
+    def read(job):
+        with open(job.src, 'rb') as f:
+            tomo, header, extended = mrc.parse(f.read())
+        return tomo.astype(np.float32), header, extended
+
+    def write(job, item, denoised):
+        # 3-D denoise refreshes the density statistics of the header (denoise.py:523-526)
+        header = item[1]._replace(mode=2, amin=denoised.min(), amax=denoised.max(), amean=denoised.mean())
+        with open(job.dst, 'wb') as f:
+            mrc.write(f, denoised, header=header, extended_header=item[2])
+    return read, write
 
 
 def denoise_tomogram(path: str, model: Denoise3D, outdir: str = None, suffix: str = '', patch_size: int = 96,
                      padding: int = 48, volume_num: int = 1, total_volumes: int = 1, gaus=None, verbose: bool = True):
-    from . import mrc
-    name = os.path.basename(path)
-    with open(path, 'rb') as f:
-        content = f.read()
-    tomo, header, extended_header = mrc.parse(content)
-    tomo = tomo.astype(np.float32)
-    denoised = model.denoise(tomo, patch_size=patch_size, padding=padding, batch_size=1, volume_num=volume_num,
+    """one tomogram; returns the INPUT volume, Gaussian-filtered when `gaus` is given -- what the reference returns
+    (it filters `tomo`, writes `denoised`: denoise.py:509,528-530)"""
+    read, write = _tomogram_io()
+    job = _Job(0, path, _output_path(path, outdir, suffix, os.path.splitext(path)[1]))
+    item = read(job)
+    denoised = model.denoise(item[0], patch_size=patch_size, padding=padding, batch_size=1, volume_num=volume_num,
                              total_volumes=total_volumes, verbose=verbose)
-    # (the reference filters `tomo`, not `denoised`, and writes `denoised`: denoise.py:509,528-529)
-    tomo = gaus.apply(tomo) if gaus is not None else tomo
-    if not outdir:
-        if suffix == '':
-            suffix = '.denoised'
-        no_ext, ext = os.path.splitext(path)
-        outpath = no_ext + suffix + ext
-    else:
-        no_ext, ext = os.path.splitext(name)
-        outpath = outdir + os.sep + no_ext + suffix + ext
-    header = header._replace(mode=2, amin=denoised.min(), amax=denoised.max(), amean=denoised.mean())
-    with open(outpath, 'wb') as f:
-        mrc.write(f, denoised, header=header, extended_header=extended_header)
-    return tomo
+    write(job, item, denoised)
+    return gaus.apply(item[0]) if gaus is not None else item[0]
 
 
 def denoise_tomogram_stream(volumes: List[str], model: Denoise3D, output_path: str, suffix: str = '', gaus: float = None,
                             patch_size: int = 96, padding: int = 48, verbose: bool = True, use_cuda: bool = True):
+    """tomograms sharded over the ranks of a multi-process launch; the next volume is read while this one is denoised"""
     from . import parallel
-    rank, _, world = parallel.init_from_env()
-    total = len(volumes)
-    denoised = []
-    if output_path is not None and output_path != '':
-        os.makedirs(output_path, exist_ok=True)
     if gaus is not None and gaus > 0:
         raise NotImplementedError('3-D Gaussian post-filter: the reference applies it to the input and discards it '
                                   '(denoise.py:509); not implemented')
-    for count, idx in enumerate(parallel.shard_indices(total, rank, world)):
-        volume = denoise_tomogram(volumes[idx], model, outdir=output_path, suffix=suffix, patch_size=patch_size,
-                                  padding=padding, volume_num=idx + 1, total_volumes=total, gaus=None, verbose=verbose)
-        denoised.append(volume)
-        print(f'# {count + 1} of {total} tomograms denoised.', file=sys.stderr, end='\r')
+    rank, _, world = parallel.init_from_env()
+    if output_path:
+        os.makedirs(output_path, exist_ok=True)
+    read, write = _tomogram_io()
+    jobs = [_Job(i, volumes[i], _output_path(volumes[i], output_path, suffix, os.path.splitext(volumes[i])[1]))
+            for i in parallel.shard_indices(len(volumes), rank, world)]
+    total = len(volumes)
+
+    inputs = []          # upstream returns the list of (unfiltered) input volumes; kept for the same return value
+
+    def process(job, item):
+        inputs.append(item[0])
+        return model.denoise(item[0], patch_size=patch_size, padding=padding, batch_size=1, volume_num=job.index + 1,
+                             total_volumes=total, verbose=verbose)
+
+    _run_jobs(jobs, read, process, write, lambda n: print(f'# {n} of {total} tomograms denoised.', file=sys.stderr, end='\r'))
     print('', file=sys.stderr)
-    return denoised
+    return inputs

@@ -82,12 +82,15 @@ def resnet_fill(mods: Sequence[dict]) -> int:
     return stride
 
 
-def pack_resnet(arch: str, sd) -> Tuple[LayerProgram, int]:
+def pack_resnet(arch: str, sd, dims: int = 2) -> Tuple[LayerProgram, int]:
+    """dims = 3: the same graph over Conv3d / BatchNorm3d weights (resnet.py:56-63,115-123; `--dims 3`)"""
     sd = _np(sd)
     mods = resnet_modules(arch)
     width = resnet_width(mods)
     resnet_fill(mods)
-    P = LayerProgram(2)
+    if sd['features.features.0.conv.weight'].ndim != dims + 2:
+        raise ValueError(f'{arch}: the weights are {sd["features.features.0.conv.weight"].ndim - 2}-D, dims = {dims} was asked for')
+    P = LayerProgram(dims)
     cur = 0
     pre0 = 'features.features.'
     head_w = sd['classifier.weight'].reshape(-1)

@@ -125,6 +125,113 @@ def as_device_f32(x, ctx: Context) -> torch.Tensor:
     return x.to(device=ctx.torch_device(), dtype=torch.float32).contiguous()
 
 
+class Stage:
+    """tpz_stage: ring of (pinned host buffer, device buffer) slots with a copy stream of its own.  The H2D copy of the
+    next image and the D2H copy of the previous result run under the current image's kernels (include/topaz_hip.h)."""
+
+    def __init__(self, ctx: Context, slot_bytes: int, depth: int = 2):
+        self.ctx, self.slot_bytes, self.depth = ctx, int(slot_bytes), int(depth)
+        h = C.c_void_p()
+        check(ctx.lib.tpz_stage_create(ctx.handle, self.slot_bytes, self.depth, C.byref(h)), ctx.handle)
+        self.handle = h
+
+    def close(self) -> None:
+        if self.handle:
+            self.ctx.lib.tpz_stage_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def host_array(self, slot: int, shape, dtype=np.float32) -> np.ndarray:
+        """numpy view of slot's pinned buffer (fill it, then upload())"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert n <= self.slot_bytes
+        p = self.ctx.lib.tpz_stage_host_ptr(self.handle, slot)
+        buf = (C.c_char * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def device_tensor(self, slot: int, shape) -> torch.Tensor:
+        """fp32 tensor aliasing slot's device buffer (valid between acquire() and release())"""
+        n = int(np.prod(shape))
+        assert 4 * n <= self.slot_bytes
+        p = self.ctx.lib.tpz_stage_device_ptr(self.handle, slot)
+        holder = _DevPtr(p, 4 * n)
+        return torch.as_tensor(holder, device=self.ctx.torch_device()).view(torch.float32).reshape(shape)
+
+    def upload(self, slot: int, nbytes: int, src: Optional[np.ndarray] = None) -> None:
+        ptr = None if src is None else np.ascontiguousarray(src).ctypes.data_as(C.c_void_p)
+        check(self.ctx.lib.tpz_stage_h2d(self.handle, slot, ptr, int(nbytes)), self.ctx.handle)
+
+    def acquire(self, slot: int) -> None:
+        self.ctx.bind_current_stream()
+        check(self.ctx.lib.tpz_stage_acquire(self.handle, slot), self.ctx.handle)
+
+    def release(self, slot: int) -> None:
+        check(self.ctx.lib.tpz_stage_release(self.handle, slot), self.ctx.handle)
+
+    def download(self, slot: int, src: torch.Tensor) -> None:
+        check(self.ctx.lib.tpz_stage_d2h(self.handle, slot, _ptr(src), src.numel() * src.element_size()), self.ctx.handle)
+
+    def wait(self, slot: int) -> None:
+        check(self.ctx.lib.tpz_stage_wait(self.handle, slot), self.ctx.handle)
+
+
+class _DevPtr:
+    """__cuda_array_interface__ holder for a raw device pointer owned by the library"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {'shape': (nbytes,), 'typestr': '|u1', 'data': (int(ptr), False), 'version': 3}
+
+
+def score_host(model: 'DeviceModel', x: np.ndarray) -> np.ndarray:
+    """tpz_score_2d_host: numpy image in, numpy logits out (synchronous; staging inside the library)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    H, W = x.shape
+    model.ctx.bind_current_stream()
+    Do, Ho, Wo = model.out_shape(1, H, W)
+    y = np.empty((Ho, Wo), dtype=np.float32)
+    check(model.ctx.lib.tpz_score_2d_host(model.handle, x.ctypes.data_as(C.c_void_p), H, W, y.ctypes.data_as(C.c_void_p)),
+          model.ctx.handle)
+    return y
+
+
+def denoise_host(model: 'DeviceModel', x: np.ndarray, patch: int, pad: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    H, W = x.shape
+    model.ctx.bind_current_stream()
+    y = np.empty_like(x)
+    check(model.ctx.lib.tpz_denoise_2d_host(model.handle, x.ctypes.data_as(C.c_void_p), H, W, int(patch), int(pad),
+                                            y.ctypes.data_as(C.c_void_p)), model.ctx.handle)
+    return y
+
+
+def nms_host(x: np.ndarray, r: int, threshold: float, ctx: Optional[Context] = None):
+    """tpz_nms_2d_host: numpy score map in, (scores, coords) numpy arrays out"""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    H, W = x.shape
+    cap = x.size if r < 1 else max(1024, min(x.size, (4 * x.size) // max(1, r * r) + 1024))
+    thr = float(threshold)
+    if thr == float('-inf'):
+        thr = -3.4028234663852886e38 * 2
+    while True:
+        coords = np.empty((cap, 2), dtype=np.int32)
+        scores = np.empty((cap,), dtype=np.float32)
+        n = C.c_int(0)
+        rc = ctx.lib.tpz_nms_2d_host(ctx.handle, x.ctypes.data_as(C.c_void_p), H, W, int(r), thr,
+                                     coords.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc != 0 and n.value > cap:
+            cap = n.value
+            continue
+        check(rc, ctx.handle)
+        return scores[:n.value].copy(), coords[:n.value].copy()
+
+
 class LayerProgram:
     """Host-side builder of the tpz_layer list + weight blob (the model manifest)."""
 
