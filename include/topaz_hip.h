@@ -104,6 +104,12 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
  * (patch+2*pad)^3 tiles normalised globally then per tile (unbiased), stitched.
  * patch < 1: the whole volume goes through _denoise. */
 int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out);
+/* One rank's share of a tomogram: only the tiles whose index (z-major over the ceil(n / patch)^3 grid, the order of
+ * PatchDataset) is == shard (mod n_shards) are denoised and pasted; the rest of d_out is left untouched (zero it first
+ * and sum the ranks' volumes).  The global mean / std are computed over the whole input by every rank -- a deterministic
+ * reduction, so all ranks normalise identically without exchanging anything. */
+int tpz_denoise_3d_shard(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, int shard, int n_shards,
+                         float* d_out);
 /* mean and std of n floats; unbiased != 0 -> divide by n-1 (torch.std), else by n (numpy.std)
  * (topaz/denoise.py:283,343,388).  h_mean_std[2] on the host; synchronises. */
 int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std);
@@ -192,6 +198,11 @@ int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float*
  * on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1 in the environment) pins the fp32 kernels.
  * tpz_model_split_stats: whether the model is eligible, images finished on the 2xf16 path, images re-run in fp32. */
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
+/* Patch lanes: tpz_denoise_2d / _3d enqueue the independent patches / tiles of an image alternately on two auxiliary
+ * streams (own workspace each), so that one patch's small, latency-bound launches run under its neighbour's large ones.
+ * On by default (TPZ_NO_LANES=1 in the environment or on = 0 here: everything on the ctx stream, e.g. to time kernels in
+ * isolation).  Results are bit-identical either way. */
+int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
 int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns);
 /* One 2-D convolution on the 2xf16 kernels with fp32 [C][H][W] tensors at the boundary (converted on the device):
  * unit-test / interop entry; arguments as tpz_conv (single source).  *overflow = 1 when a result left the f16 range. */

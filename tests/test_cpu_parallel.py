@@ -107,3 +107,41 @@ def test_launch_local_ranks_propagates_failure():
     assert launch_local_ranks(2, [sys.executable, '-c', code]) == 3        # rank 0 is terminated, not waited for
     assert time.time() - t0 < 30
     assert launch_local_ranks(2, [sys.executable, '-c', 'import os; assert "RANK" in os.environ']) == 0
+
+
+def _sum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from topaz_amd import parallel
+    parallel.init_from_env('gloo')
+    # each rank owns the tiles t = rank (mod world) of a 4 x 4 x 4 tile grid of 8^3 tiles
+    vol = torch.zeros(32, 32, 32)
+    t = 0
+    for i in range(0, 32, 8):
+        for j in range(0, 32, 8):
+            for k in range(0, 32, 8):
+                if t % world == rank:
+                    vol[i:i + 8, j:j + 8, k:k + 8] = float(t + 1)
+                t += 1
+    out = parallel.sum_to_root(vol)
+    if rank == 0:
+        want = torch.arange(1, 65, dtype=torch.float32).reshape(4, 4, 4).repeat_interleave(8, 0).repeat_interleave(8, 1).repeat_interleave(8, 2)
+        q.put(bool(torch.equal(out, want)))
+    else:
+        assert out is None
+    torch.distributed.destroy_process_group()
+
+
+def test_sum_to_root_assembles_tile_sharded_volume_world2_gloo():
+    """the exchange step of tile-sharded tomogram denoising: every voxel is non-zero on exactly one rank, one reduce onto
+    rank 0 assembles the volume"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -152,3 +152,23 @@ def test_edge_cases(gpu_ctx):
     # constant image: std = 0 -> the reference returns NaN everywhere; so do we
     y = d.denoise(np.full((40, 40), 3.0, dtype=np.float32), -1)
     assert np.isnan(y).all()
+
+
+def test_tomogram_tiles_sharded_like_ranks_would(gpu_ctx):
+    """tpz_denoise_3d_shard: the tiles of one tomogram dealt round-robin to n shards (what n ranks do, each followed by one
+    RCCL reduce onto rank 0) -- the shards' volumes are disjoint and their sum is bit-identical to the unsharded result"""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    z = load_golden('denoise3d_unet3d_nf8')
+    d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+    tomo = torch.from_numpy(z['tomo']).cuda()
+    dm = d.model.device_model
+    whole = dm.denoise_3d(tomo, 32, 16)
+    for n in (2, 3):
+        parts = [dm.denoise_3d(tomo, 32, 16, shard=k, n_shards=n) for k in range(n)]
+        covered = sum((p != 0).to(torch.int32) for p in parts)
+        assert int(covered.max()) <= 1                       # no voxel written by two shards
+        assert torch.equal(sum(parts), whole)
+    assert np.abs(whole.cpu().numpy() - z['p32_16']).max() <= ATOL
+    with pytest.raises(Exception, match='cannot be sharded'):
+        dm.denoise_3d(tomo, -1, 0, shard=0, n_shards=2)

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'tpz_model_out_channels': (C.c_int, [_P, C.POINTER(C.c_int)]),
     'tpz_denoise_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_denoise_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    'tpz_denoise_3d_shard': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_mean_std': (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     'tpz_gmm_fit': (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
                               _P, _P, _P, _P]),
@@ -73,6 +74,7 @@ _SIGNATURES = {
     'tpz_maxpool2': (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     'tpz_transpose_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     'tpz_ctx_set_exact': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_lanes': (C.c_int, [_P, C.c_int]),
     'tpz_model_split_stats': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'tpz_conv_split_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_int)]),

@@ -97,6 +97,7 @@ struct tpz_ctx {
     hipStream_t lanes_saved_stream = nullptr;
     double* lanes_saved_part = nullptr;
     bool lanes_on = false;
+    bool lanes_enabled = !g_no_lanes;         // tpz_ctx_set_lanes
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
@@ -179,7 +180,7 @@ static float* next_nrm(tpz_ctx* ctx) {
 
 // ---- patch lanes (tpz_ctx::Lane)
 static int lanes_begin(tpz_ctx* ctx) {
-    if (g_no_lanes || ctx->lanes_on) return 0;
+    if (!ctx->lanes_enabled || ctx->lanes_on) return 0;
     if (!ctx->lanes_fork) {
         if (hipEventCreateWithFlags(&ctx->lanes_fork, hipEventDisableTiming) != hipSuccess) return fail(ctx, "hipEventCreate failed");
         for (auto& ln : ctx->lanes) {
@@ -1670,6 +1671,12 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
     return 0;
 }
 
+int tpz_ctx_set_lanes(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    ctx->lanes_enabled = on != 0;
+    return 0;
+}
+
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     ctx->exact = (on != 0) || g_exact_fp32;
@@ -1836,7 +1843,7 @@ int tpz_denoise_2d(tpz_model* m, const float* d_in, int H, int W, int patch, int
 }
 
 static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out,
-                           bool split) {
+                           bool split, int shard = 0, int n_shards = 1) {
     tpz_ctx* ctx = m->ctx;
     if (patch < 1) {
         Slot v;
@@ -1858,10 +1865,11 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
         touts[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
         if (!tiles[l] || !touts[l]) rc = fail(ctx, "out of device memory");
     }
-    int n_tile = 0;
+    int n_tile = 0, tile_index = 0;
     for (int i = 0; i < D && !rc; i += patch)
         for (int j = 0; j < H && !rc; j += patch)
             for (int k = 0; k < W && !rc; k += patch) {
+                if (tile_index++ % n_shards != shard) continue;        // another rank's tile
                 const int l = n_tile++ % n_lanes;
                 lane_enter(ctx, l);
                 float *tile = tiles[l], *tout = touts[l];
@@ -1891,20 +1899,26 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     return rc;
 }
 
-int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
+int tpz_denoise_3d_shard(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, int shard, int n_shards,
+                         float* d_out) {
     if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_denoise_3d: NULL argument");
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) return fail(m->ctx, "tpz_denoise_3d_shard: shard %d of %d", shard, n_shards);
+    if (patch < 1 && n_shards > 1) return fail(m->ctx, "tpz_denoise_3d_shard: an untiled volume cannot be sharded");
     tpz_ctx* ctx = m->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (m->split_ok && !ctx->exact) {
         // 2xf16 path for the whole tomogram; any activation beyond the f16 range re-runs it on the fp32 kernels
         HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
-        if (denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, true)) return 1;
+        if (denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, true, shard, n_shards)) return 1;
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (*ctx->h_flag == 0) { ++m->n_split; return 0; }
         ++m->n_fallback;
     }
-    return denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, false);
+    return denoise_3d_pass(m, d_in, D, H, W, patch, pad, d_out, false, shard, n_shards);
+}
+int tpz_denoise_3d(tpz_model* m, const float* d_in, int D, int H, int W, int patch, int pad, float* d_out) {
+    return tpz_denoise_3d_shard(m, d_in, D, H, W, patch, pad, 0, 1, d_out);
 }
 
 int tpz_mean_std(tpz_ctx* ctx, const float* d_x, size_t n, int unbiased, float* h_mean_std) {

@@ -94,9 +94,21 @@ class Denoise3D(Denoise):
         super().__init__(model, use_cuda, dims=3)
 
     def denoise(self, tomo: np.ndarray, patch_size: int = 96, padding: int = 48, batch_size: int = 1,
-                volume_num: int = 1, total_volumes: int = 1, verbose: bool = True) -> np.ndarray:
+                volume_num: int = 1, total_volumes: int = 1, verbose: bool = True, across_ranks: bool = False) -> np.ndarray:
+        """across_ranks=True (multi-process launch, every rank holding the same tomogram): the ceil(n / patch)^3 tiles are
+        dealt round-robin to the ranks -- they are independent (datasets.py:412-468), the global mean / std every rank
+        computes over the whole volume is the same deterministic reduction -- and the ranks' partial volumes are summed onto
+        rank 0 with one RCCL reduce; the other ranks return None."""
         x = self._to_device(tomo)
-        y = self.model.device_model.denoise_3d(x, patch_size, padding)
+        dm = self.model.device_model
+        if across_ranks and patch_size >= 1:
+            from . import parallel
+            rank, _, world = parallel.init_from_env()
+            y = parallel.sum_to_root(dm.denoise_3d(x, patch_size, padding, shard=rank, n_shards=world))
+            if y is None:
+                return None
+        else:
+            y = dm.denoise_3d(x, patch_size, padding)
         if verbose:
             print(f'# [{volume_num}/{total_volumes}] 100%', file=sys.stderr, end='\r')
             print(' ' * 100, file=sys.stderr, end='\r')
@@ -261,7 +273,8 @@ def denoise_tomogram(path: str, model: Denoise3D, outdir: str = None, suffix: st
 
 def denoise_tomogram_stream(volumes: List[str], model: Denoise3D, output_path: str, suffix: str = '', gaus: float = None,
                             patch_size: int = 96, padding: int = 48, verbose: bool = True, use_cuda: bool = True):
-    """tomograms sharded over the ranks of a multi-process launch; the next volume is read while this one is denoised"""
+    """tomograms (or, when there are fewer tomograms than ranks, their tiles) sharded over the ranks of a multi-process
+    launch; the next volume is read while this one is denoised"""
     from . import parallel
     if gaus is not None and gaus > 0:
         raise NotImplementedError('3-D Gaussian post-filter: the reference applies it to the input and discards it '
@@ -270,16 +283,25 @@ def denoise_tomogram_stream(volumes: List[str], model: Denoise3D, output_path: s
     if output_path:
         os.makedirs(output_path, exist_ok=True)
     read, write = _tomogram_io()
-    jobs = [_Job(i, volumes[i], _output_path(volumes[i], output_path, suffix, os.path.splitext(volumes[i])[1]))
-            for i in parallel.shard_indices(len(volumes), rank, world)]
     total = len(volumes)
-
+    # fewer tomograms than ranks: split each tomogram's TILES over all ranks instead of leaving ranks idle (a 512x512x256
+    # volume is 108 independent 192^3 tiles); otherwise whole tomograms are dealt to the ranks
+    by_tiles = world > 1 and total < world and patch_size >= 1
+    mine = range(total) if by_tiles else parallel.shard_indices(total, rank, world)
+    jobs = [_Job(i, volumes[i], _output_path(volumes[i], output_path, suffix, os.path.splitext(volumes[i])[1])) for i in mine]
     inputs = []          # upstream returns the list of (unfiltered) input volumes; kept for the same return value
 
     def process(job, item):
         inputs.append(item[0])
         return model.denoise(item[0], patch_size=patch_size, padding=padding, batch_size=1, volume_num=job.index + 1,
-                             total_volumes=total, verbose=verbose)
+                             total_volumes=total, verbose=verbose and rank == 0, across_ranks=by_tiles)
+
+    if by_tiles:
+        plain_write = write
+
+        def write(job, item, denoised):            # only rank 0 holds the assembled volume
+            if denoised is not None:
+                plain_write(job, item, denoised)
 
     _run_jobs(jobs, read, process, write, lambda n: print(f'# {n} of {total} tomograms denoised.', file=sys.stderr, end='\r'))
     print('', file=sys.stderr)

@@ -111,6 +111,16 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def sum_to_root(t: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
+    """element-wise sum of every rank's tensor onto rank `dst` (one reduce; RCCL on device tensors, gloo on host ones).
+    Used to assemble a tomogram whose tiles were denoised by different ranks: each voxel is non-zero on exactly one rank, so
+    the sum is exact.  Returns the tensor on dst, None elsewhere; a single process returns its tensor unchanged."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    return t if dist.get_rank() == dst else None
+
+
 def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor], coords: Sequence[torch.Tensor],
                        device: torch.device, dst: int = 0):
     """Gather per-image pick tables to rank `dst`.

@@ -70,6 +70,10 @@ class Context:
         """pin the fp32 MFMA kernels (no 2xf16 path) for models run on this context"""
         check(self.lib.tpz_ctx_set_exact(self.handle, 1 if on else 0), self.handle)
 
+    def set_lanes(self, on: bool = True) -> None:
+        """patch lanes of tpz_denoise_2d / _3d (two auxiliary streams); off: every launch on the ctx stream"""
+        check(self.lib.tpz_ctx_set_lanes(self.handle, 1 if on else 0), self.handle)
+
     def prof_get(self, cls: int) -> Tuple[float, int, float]:
         ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
         check(self.lib.tpz_prof_get(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)), self.handle)
@@ -366,13 +370,14 @@ class DeviceModel:
         check(self.ctx.lib.tpz_denoise_2d(self.handle, _ptr(x), H, W, int(patch), int(pad), _ptr(y)), self.ctx.handle)
         return y
 
-    def denoise_3d(self, x: torch.Tensor, patch: int, pad: int) -> torch.Tensor:
+    def denoise_3d(self, x: torch.Tensor, patch: int, pad: int, shard: int = 0, n_shards: int = 1) -> torch.Tensor:
+        """n_shards > 1: only this shard's tiles are denoised; the rest of the returned volume is zero (sum the shards)"""
         self.ctx.bind_current_stream()
         x = as_device_f32(x, self.ctx)
         D, H, W = x.shape
-        y = torch.empty_like(x)
-        check(self.ctx.lib.tpz_denoise_3d(self.handle, _ptr(x), D, H, W, int(patch), int(pad), _ptr(y)),
-              self.ctx.handle)
+        y = torch.empty_like(x) if n_shards == 1 else torch.zeros_like(x)
+        check(self.ctx.lib.tpz_denoise_3d_shard(self.handle, _ptr(x), D, H, W, int(patch), int(pad), int(shard), int(n_shards),
+                                                _ptr(y)), self.ctx.handle)
         return y
 
 
