@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
 #include "conv_split.h"
 using namespace tpz;
 
@@ -87,7 +88,70 @@ int bench(const char* name, int cin, int cout, int H) {
     return 0;
 }
 
-int main() {
+template <class C, int EPI>
+int quick(const char* name, int cin, int cout, int H) {
+    const int span = C::D * (C::K - 1);
+    const int Ho = H - span;
+    const size_t cells_in = (cin + 7) / 8, cells_out = (cout + 7) / 8;
+    const size_t n_in = cells_in * 8 * H * H, n_out = cells_out * 8 * (size_t)Ho * Ho;
+    const int n_cog = (cout + C::MT - 1) / C::MT, n_chunks = (int)((cells_in + C::CC - 1) / C::CC);
+    const int n_st = C::CONT ? C::cont_stages((int)cells_in) : n_chunks * C::NSTEP;
+    const size_t n_w = (size_t)n_cog * n_st * C::W_STEP_BYTES / 4;
+    float *in, *w, *out, *res, *zeros, *vec;
+    unsigned* flag;
+    CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 64));
+    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 64));
+    // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
+    std::vector<uint16_t> h(1 << 21);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x2800 + ((i * 2654435761u) >> 20) % 0x1000) | (uint16_t)(((i * 40503u) >> 7) & 1) << 15;
+    for (size_t o = 0; o < n_in * 4; o += h.size() * 2) CHK(hipMemcpy((char*)in + o, h.data(), std::min(h.size() * 2, n_in * 4 - o), hipMemcpyHostToDevice));
+    for (size_t o = 0; o < n_w * 4; o += h.size() * 2) CHK(hipMemcpy((char*)w + o, h.data(), std::min(h.size() * 2, n_w * 4 - o), hipMemcpyHostToDevice));
+    for (size_t o = 0; o < n_out * 4; o += h.size() * 2) CHK(hipMemcpy((char*)res + o, h.data(), std::min(h.size() * 2, n_out * 4 - o), hipMemcpyHostToDevice));
+    std::vector<float> ones(cout, 1e-3f);
+    CHK(hipMemcpy(vec, ones.data(), cout * 4, hipMemcpyHostToDevice));
+    SplitArgs a{};
+    a.in = (const uint4*)in; a.wpk = (const uint4*)w; a.wscale = vec; a.bias = vec; a.out = (uint4*)out; a.res = (const uint4*)res;
+    a.post_scale = vec; a.post_shift = vec; a.head_w = vec; a.head_out = out; a.zeros = zeros; a.flag = flag;
+    a.cells_in = a.cells_in1 = (int)cells_in; a.Hin = a.H1 = H; a.Win = a.W1 = H; a.Cout = cout; a.cells_out = (int)cells_out; a.Hout = Ho; a.Wout = Ho;
+    a.os = 1; a.Hfull = Ho; a.Wfull = Ho; a.Hres = Ho; a.Wres = Ho; a.n_chunks = n_chunks; a.xcd_swizzle = 1;
+    a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
+    a.tiles_x = (Ho + C::TW - 1) / C::TW;
+    a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
+    dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
+    const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
+    printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
+           n_st * a.cog_inner);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(flag, 0, 64);
+        float ms = run<C, EPI, 2048>(a, grid, 10);
+        unsigned long long c[4];
+        hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost);
+        printf("  run %d  %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", rep, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0);
+    }
+    hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(zeros); hipFree(vec); hipFree(flag);
+    return 0;
+}
+
+
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "stages") {
+        // steps per stage (barrier every S steps), same layer, same process
+        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D2 MT64 8w S=1", 64, 64, 2048);
+        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w S=2", 64, 64, 2048);
+        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 4>, EPI_PLAIN>("K3 D2 MT64 8w S=4", 64, 64, 2048);
+        quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 1>, EPI_RES>("K3 D4 MT64 8w RES S=1", 64, 64, 2048);
+        quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w RES S=2", 64, 64, 2048);
+        quick<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 1>, EPI_PLAIN>("K5 D1 MT32 4w S=1", 64, 32, 2048);
+        quick<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2", 64, 32, 2048);
+        quick<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w S=1", 96, 96, 1024);
+        quick<SplitCfg<3, 1, 48, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT48 4w S=1", 48, 48, 1024);
+        quick<SplitCfg<3, 1, 48, 8, 32, 2, 4, 3, 2>, EPI_PLAIN>("K3 D1 MT48 4w S=2", 48, 48, 1024);
+        quick<SplitCfg<3, 4, 128, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D4 MT128 8w S=1", 128, 128, 2048);
+        quick<SplitCfg<3, 4, 128, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D4 MT128 8w S=2", 128, 128, 2048);
+        return 0;
+    }
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_RES>("K3 D4 MT128 RES (ResNet8 block2 conv1)", 64, 128, 2048);
     bench<SplitCfg<3, 4, 128, 16, 32, 2>, EPI_PLAIN>("K3 D4 MT128 PLAIN", 128, 128, 2048);
     bench<SplitCfg<5, 4, 128, 16, 32, 2>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);

@@ -96,7 +96,7 @@ struct SplitSlot {
 
 // K x KX taps (rows x columns; KX = K for the square kernels, KX = 1 for the column kernels that carry the x taps of
 // a stem as input channels or of a 1-output-channel conv as output channels, runtime.hip)
-template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8, int KX_ = K_>
+template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8, int KX_ = K_, int SPS_ = 1>
 struct SplitCfg {
     static constexpr int K = K_, KX = KX_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
     // 8 waves: one workgroup per CU (the big dilated tiles need most of the LDS); 4 waves: two per CU, so that
@@ -153,9 +153,14 @@ struct SplitCfg {
         return (s.c * CELL_STRIDE + s.ky * ITW + s.kx * D) * 16;
     }
     static constexpr int W_STEP_BYTES = 2 * MW * 1024;              // hi + lo A fragments of one step
-    static constexpr int WR = (W_STEP_BYTES + THREADS * 16 - 1) / (THREADS * 16);   // DMA rounds per weight step
+    // A STAGE is SPS consecutive steps between two workgroup barriers: its weights (SPS * W_STEP_BYTES, contiguous in the
+    // packed array) arrive by DMA during the previous stage.  Narrow channel tiles (MT <= 64: 24 - 48 MFMAs per wave and
+    // step) would otherwise synchronise every 400 - 800 cycles.
+    static constexpr int SPS = SPS_;
+    static constexpr int W_STAGE_BYTES = SPS * W_STEP_BYTES;
+    static constexpr int WR = (W_STAGE_BYTES + THREADS * 16 - 1) / (THREADS * 16);  // DMA rounds per weight stage
     static constexpr int OFF_W = 2 * IN_BUF;
-    static constexpr int OFF_TAB = OFF_W + 2 * W_STEP_BYTES;
+    static constexpr int OFF_TAB = OFF_W + 2 * W_STAGE_BYTES;
     static constexpr int OFF_SLOT = OFF_TAB + NPC * 4;
     static constexpr int N_SLOT_TAB = CONT ? Q : NSTEP * 4;
     static constexpr int LDS_BYTES = OFF_SLOT + (N_SLOT_TAB + 3) / 4 * 16;
@@ -163,6 +168,7 @@ struct SplitCfg {
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
     static_assert(LDS_BYTES <= 160 * 1024 / WGS_PER_CU, "LDS per workgroup");
     static_assert(WAVES == 8 || WAVES == 4, "waves per workgroup");
+    static_assert(SPS == 1 || (CONT && Q >= 4 * SPS), "multi-step stages: continuous slot stream, chunks of >= SPS steps");
 };
 
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
@@ -307,12 +313,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             }
         }
     };
-    auto issue_weights = [&](const unsigned char* wcog, int st, int buf, int tid, int wave) {
-        const void* base = uniform_ptr(wcog + (size_t)st * C::W_STEP_BYTES);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STEP_BYTES + wave * 1024));
+    // weights of stage `stg` (its steps that exist: `bytes` = min(SPS, steps left) * W_STEP_BYTES) -> weight buffer `buf`
+    auto issue_weights = [&](const unsigned char* wcog, int stg, int bytes, int buf, int tid, int wave) {
+        const void* base = uniform_ptr(wcog + (size_t)stg * C::W_STAGE_BYTES);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STAGE_BYTES + wave * 1024));
 #pragma unroll
         for (int i = 0; i < C::WR; ++i)
-            if ((i * C::WAVES + wave) * 1024 < C::W_STEP_BYTES)       // whole waves (1 KiB each)
+            if ((i * C::WAVES + wave) * 1024 < bytes)                  // whole waves (1 KiB each)
                 glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
     };
 
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         compute_offsets(chunks1 == 0);
 #pragma unroll 1
         for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r, tid, wave);
-        issue_weights(wcog, 0, 0, tid, wave);
+        issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid, wave);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
@@ -385,17 +392,21 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 
 #pragma unroll 1
         for (int s = 0; s < n_stages; ++s) {
-            // chunk of the step's first slot; pf = chunk whose tile is being prefetched, r0 / rstride = its DMA rounds
+            const int stage = s / C::SPS, sub = s - stage * C::SPS;      // (SPS = 1: stage = s, sub = 0)
+            const bool stage_end = sub == C::SPS - 1 || s == n_stages - 1;
+            // chunk of the stage's first slot; pf = chunk whose tile is being prefetched, r0 / rstride = its DMA rounds
             int ch, pf, r0, rstride;
             if constexpr (C::CONT) {
                 ch = (4 * s) / C::Q;
                 pf = ch + 1;
                 // buffer pf & 1 is free once the last slot of chunk pf - 2 is done and must be full before the first
-                // slot of chunk pf: stages [ws, we]; the step that straddles two chunks issues nothing
+                // slot of chunk pf: steps [ws, we], i.e. the stages that lie wholly inside them; a stage that straddles
+                // two chunks issues nothing
                 const int ws = pf >= 2 ? (C::Q * (pf - 1) - 1) / 4 + 1 : 0;
                 const int we = (C::Q * pf) / 4 - 1;
-                r0 = (s >= ws && s <= we) ? s - ws : C::NR;
-                rstride = we - ws + 1;
+                const int gs = (ws + C::SPS - 1) / C::SPS, ge = (we + 1) / C::SPS - 1;
+                r0 = (stage >= gs && stage <= ge) ? stage - gs : C::NR;
+                rstride = ge - gs + 1;
             } else {
                 ch = s / C::NSTEP;
                 pf = ch + 1;
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 rstride = C::NSTEP;
             }
             // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
-            if constexpr (!(ABL & 2)) {
+            if (!(ABL & 2) && sub == 0) {
                 // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
                 // start their MFMAs at once and keep the matrix core busy meanwhile)
                 const bool iss = a.issuer_half && C::WAVES == 8 && !a.in2;
@@ -411,7 +422,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 if constexpr (!(ABL & 128)) {
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
-                        if (s + 1 < n_stages) issue_weights(wcog, s + 1, (s + 1) & 1, vt, vw);
+                        const int left = n_stages - (stage + 1) * C::SPS;            // steps of the next stage
+                        if (left > 0) issue_weights(wcog, stage + 1, (left < C::SPS ? left : C::SPS) * C::W_STEP_BYTES, (stage + 1) & 1, vt, vw);
                     }
                 }
                 if (!(ABL & 256) && pf < a.n_chunks && r0 < C::NR) {
@@ -432,8 +444,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             //   barrier (150 - 250 cycles of a step of 768 (MT = 64) ... 3072 (MT = 128, 8 waves) cycles).
             //   MFMA order within a channel fragment: ah*bo, ah*bh, ao*bh -- the lo halves of B are released first.
             const unsigned char* bl_next = b_frag_base(s + 1 < n_stages ? s + 1 : s);      // (slot-table lookup: early)
-            const unsigned char* al = lds + a_lane + (s & 1) * C::W_STEP_BYTES;
-            const unsigned char* al_next = lds + a_lane + ((s + 1) & 1) * C::W_STEP_BYTES;
+            const unsigned char* al = lds + a_lane + (stage & 1) * C::W_STAGE_BYTES + sub * C::W_STEP_BYTES;
+            const int stage_n = (s + 1) / C::SPS;
+            const unsigned char* al_next = lds + a_lane + (stage_n & 1) * C::W_STAGE_BYTES + (s + 1 - stage_n * C::SPS) * C::W_STEP_BYTES;
             constexpr bool A0_EARLY = (MW % 2 == 0);          // slot 0 of ah / ao is free during the last fragment (slot 1)
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
@@ -459,8 +472,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this step has landed
-                    if constexpr (!(ABL & 4)) __syncthreads();
+                    if (C::SPS == 1 || stage_end) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this stage has landed
+                        if constexpr (!(ABL & 4)) __syncthreads();
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const bool last = m + 1 == MW;

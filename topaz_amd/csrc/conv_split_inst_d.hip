@@ -7,8 +7,8 @@
 TPZ_SPLIT4(3, 1, 48, 8, 32, 2, ::tpz::EPI_PLAIN)
 TPZ_SPLIT4(3, 1, 96, 8, 32, 2, ::tpz::EPI_PLAIN)
 TPZ_SPLIT4(2, 1, 96, 8, 32, 2, ::tpz::EPI_RES)
-TPZ_SPLIT4(5, 1, 32, 8, 32, 2, ::tpz::EPI_PLAIN_F32)
-TPZ_SPLIT4(5, 1, 32, 8, 32, 2, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4_S(5, 1, 32, 8, 32, 2, 2, ::tpz::EPI_PLAIN_F32)
+TPZ_SPLIT4_S(5, 1, 32, 8, 32, 2, 2, ::tpz::EPI_PLAIN)
 // UDenoiseNet3D (plane-stacked 3-D, conv_split.h): dec1.0 parity kernels (2 taps per axis, 64 outputs) and dec1.2
 // storing fp32 for the 1-channel last conv; the 48 / 96-channel 3x3(x3) and 2x2(x2) kernels above are shared
 TPZ_SPLIT4(2, 1, 64, 8, 32, 2, ::tpz::EPI_RES)

@@ -8,7 +8,7 @@ namespace tpz {
 
 struct SplitKernelInfo {
     int K, D, MT, epi;
-    int KX, TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes;
+    int KX, TH, TW, CC, WAVES, NSTEP, W_STEP_BYTES, lds_bytes, SPS;
     int cont, Q;                               // continuous slot stream (SplitCfg::CONT): Q slots per chunk
     SplitSlot (*slot)(int step, int kb);
     SplitSlot (*cont_slot)(int q);
@@ -46,24 +46,38 @@ struct SplitRegistrar {
         i.K = C::K; i.KX = C::KX; i.D = C::D; i.MT = C::MT; i.epi = EPI;
         i.TH = C::TH; i.TW = C::TW; i.CC = C::CC; i.WAVES = C::WAVES; i.NSTEP = C::NSTEP; i.W_STEP_BYTES = C::W_STEP_BYTES;
         i.lds_bytes = C::LDS_BYTES;
+        i.SPS = C::SPS;
         i.slot = &split_slot_of<C>;
         i.cont = C::CONT ? 1 : 0; i.Q = C::Q;
         i.cont_slot = &split_cont_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
-        snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,
-                 i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.epi);
+        if (C::SPS == 1)
+            snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,
+                     i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.epi);
+        else
+            snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,S=%d,EPI=%d>", i.K,
+                     i.KX, i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.SPS, i.epi);
         register_split(i);
     }
 };
 
 #define TPZ_SPLIT(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+// S steps per stage (barrier every S steps): narrow channel tiles
+#define TPZ_SPLIT_S(K, D, MT, TH, TW, CC, S, EPI) \
+    static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 8, K, S>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+#define TPZ_SPLIT4_S(K, D, MT, TH, TW, CC, S, EPI) \
+    static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4, K, S>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
 // column kernels (K x 1 taps), 4-wave workgroups
 #define TPZ_SPLIT4_COL(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4, 1>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
 // 4-wave workgroups, two per CU
 #define TPZ_SPLIT4(K, D, MT, TH, TW, CC, EPI) \
     static ::tpz::SplitRegistrar<::tpz::SplitCfg<K, D, MT, TH, TW, CC, 4>, EPI> TPZ_CAT(tpz_sreg_, __COUNTER__);
+#define TPZ_SPLIT_RESID_S(K, D, MT, TH, TW, CC, S)        \
+    TPZ_SPLIT_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_PLAIN) \
+    TPZ_SPLIT_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_RES)   \
+    TPZ_SPLIT_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_RES_POST)
 #define TPZ_SPLIT4_RESID(K, D, MT, TH, TW, CC)        \
     TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \
     TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_RES)   \
