@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-instantiation time and achieved TFLOP/s of the conv_mfma kernels for one workload, single lane, measured
+"""Per-instantiation time and achieved TFLOP/s of the convolution kernels for one workload, patch lanes off, measured
 with the library's own HIP-event profiler (tpz_prof_*):   python tools/prof_kernels.py [denoise|extract|denoise3d]"""
 import os
 import sys
@@ -32,6 +32,7 @@ def main(what):
         fn = lambda: d3.model.device_model.denoise_3d(t, 96, 48)
     fn()
     torch.cuda.synchronize()
+    ctx.set_lanes(False)            # kernels timed in isolation: no concurrent patch streams
     ctx.prof_enable(True)
     ctx.prof_reset()
     fn()

@@ -140,7 +140,6 @@ int main(int argc, char** argv) {
         // steps per stage (barrier every S steps), same layer, same process
         quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D2 MT64 8w S=1", 64, 64, 2048);
         quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w S=2", 64, 64, 2048);
-        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 4>, EPI_PLAIN>("K3 D2 MT64 8w S=4", 64, 64, 2048);
         quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 1>, EPI_RES>("K3 D4 MT64 8w RES S=1", 64, 64, 2048);
         quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w RES S=2", 64, 64, 2048);
         quick<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 1>, EPI_PLAIN>("K5 D1 MT32 4w S=1", 64, 32, 2048);

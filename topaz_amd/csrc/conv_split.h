@@ -168,7 +168,8 @@ struct SplitCfg {
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
     static_assert(LDS_BYTES <= 160 * 1024 / WGS_PER_CU, "LDS per workgroup");
     static_assert(WAVES == 8 || WAVES == 4, "waves per workgroup");
-    static_assert(SPS == 1 || (CONT && Q >= 4 * SPS), "multi-step stages: continuous slot stream, chunks of >= SPS steps");
+    // every chunk's prefetch window (~ Q / 4 - 1 steps) must contain at least one whole, aligned stage
+    static_assert(SPS == 1 || (CONT && Q >= 8 * SPS), "multi-step stages: continuous slot stream, chunks of >= 2 * SPS steps");
 };
 
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);

@@ -3,5 +3,5 @@
 // d = 2, 4: 8-wave (measured equal or faster there)
 //                K  D  MT  TH  TW  CC
 TPZ_SPLIT4_RESID(3, 1, 64, 8,  32, 2)
-TPZ_SPLIT_RESID_S(3, 2, 64, 16, 32, 2, 4)
+TPZ_SPLIT_RESID_S(3, 2, 64, 16, 32, 2, 2)
 TPZ_SPLIT_RESID_S(3, 4, 64, 16, 32, 2, 2)

@@ -32,12 +32,14 @@ hipError_t launch_extract_tile3d(const float* tomo, int D, int H, int W, int i0,
 
 hipError_t nms_mark(const float* score, size_t n, float thr, uint8_t* status, uint32_t* cand, unsigned int* counters,
                     hipStream_t s);
-hipError_t nms2d_sweep(const float* score, int H, int W, int r, const int* halfw, const int* cells, int ncells, uint8_t* status,
-                       const uint32_t* list_in, uint32_t* list_out, unsigned int* cnt, unsigned int* snap, uint64_t* keys,
-                       unsigned int* npicks, size_t hint, hipStream_t s);
-hipError_t nms3d_sweep(const float* score, long long n, const int* deltas, int ndelta, uint8_t* status,
-                       const uint32_t* list_in, uint32_t* list_out, unsigned int* cnt, unsigned int* snap, uint64_t* keys,
-                       unsigned int* npicks, size_t hint, hipStream_t s);
+hipError_t nms2d_sweep(const float* score, int H, int W, const int* near_cells, int n_near, const int* cells, int ncells,
+                       uint8_t* status, const uint32_t* list_in, uint32_t* list_out, uint32_t* list_ver, unsigned int* cnt,
+                       unsigned int* cnt_ver, unsigned int* snap, uint64_t* keys, unsigned int* npicks, size_t hint,
+                       hipStream_t s);
+hipError_t nms3d_sweep(const float* score, long long n, const int* near_deltas, int n_near, const int* deltas, int ndelta,
+                       uint8_t* status, const uint32_t* list_in, uint32_t* list_out, uint32_t* list_ver, unsigned int* cnt,
+                       unsigned int* cnt_ver, unsigned int* snap, uint64_t* keys, unsigned int* npicks, size_t hint,
+                       hipStream_t s);
 hipError_t fill_u64(uint64_t* p, size_t lo, size_t hi, uint64_t v, hipStream_t s);
 hipError_t bitonic_sort_desc(uint64_t* keys, size_t npow2, hipStream_t s);
 hipError_t nms_write(const uint64_t* keys, unsigned int n, const float* score, int H, int W, int dims,

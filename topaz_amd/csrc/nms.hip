@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void nms_mark_kernel(const float* __restrict__
 //         will suppress p, if it is UNDECIDED p has to wait).  Rows nearest first and, inside a row, columns
 //         nearest first: in a dense candidate field an immediate neighbour is higher half of the time, so
 //         most candidates stop after one or two probes.
-//   select: a p with no such neighbour is SELECTED; its sort key goes straight to the pick list.
+//   select: a p with no such neighbour is SELECTED; its sort key goes straight to the pick list.  (Two kernels: a cheap
+//         per-thread filter over the nearest cells, then one wave per survivor over the whole set -- a thread scanning the
+//         ~pi r^2 cells of a local maximum alone kept its wave busy for hundreds of dependent probes.)
 //   push (nms2d_push_kernel, after the sweep): every new pick marks the lower-priority candidates of Supp(p)
 //         SUPPRESSED (including the column-0-of-the-next-row cells of the right-edge quirk).
 //   Candidates that stay undecided are appended to the next sweep's list (wave-aggregated atomics), so sweep k
@@ -96,22 +98,6 @@ __device__ __forceinline__ bool nms_higher(const float* __restrict__ score, cons
     const uint8_t st = status[q];
     if (st == ST_NONE || st == ST_SUPPRESSED) return false;
     return prio_key(score[q], q) > kp;
-}
-__device__ __forceinline__ bool nms2d_blocks(const float* __restrict__ score, const uint8_t* status, size_t rowb,
-                                             int x_lo, int x_hi, uint64_t kp) {
-    for (int qx = x_lo; qx <= x_hi; ++qx)
-        if (nms_higher(score, status, (uint32_t)(rowb + qx), kp)) return true;
-    return false;
-}
-// the same over [px - hw, px + hw] clipped to the row, nearest column first
-__device__ __forceinline__ bool nms2d_blocks_near(const float* __restrict__ score, const uint8_t* status, size_t rowb,
-                                                  int px, int hw, int W, bool self_row, uint64_t kp) {
-    if (!self_row && nms_higher(score, status, (uint32_t)(rowb + px), kp)) return true;
-    for (int d = 1; d <= hw; ++d) {
-        if (px - d >= 0 && nms_higher(score, status, (uint32_t)(rowb + px - d), kp)) return true;
-        if (px + d < W && nms_higher(score, status, (uint32_t)(rowb + px + d), kp)) return true;
-    }
-    return false;
 }
 // append to a device list: one atomic per wave
 __device__ __forceinline__ void list_append(bool pred, uint32_t v, uint32_t* __restrict__ list, unsigned int* cnt) {
@@ -124,96 +110,206 @@ __device__ __forceinline__ void list_append(bool pred, uint32_t v, uint32_t* __r
         if (pred) list[pos + __popcll(m & ((1ull << lane) - 1ull))] = v;
     }
 }
-__device__ __forceinline__ void keys_append(bool pred, uint64_t v, uint64_t* __restrict__ list, unsigned int* cnt) {
-    const unsigned long long m = __ballot(pred);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned int pos = 0;
-        if (lane == __ffsll((long long)m) - 1) pos = atomicAdd(cnt, (unsigned int)__popcll(m));
-        pos = __shfl(pos, __ffsll((long long)m) - 1, 64);
-        if (pred) list[pos + __popcll(m & ((1ull << lane) - 1ull))] = v;
+// ---- sweep, phase A (one THREAD per still-undecided candidate): probe only the nearest cells of the suppressor set (the
+// 5 x 5 neighbourhood clipped to the disk / the +-1 cube clipped to the ball, nearest first).  Every candidate that is still
+// undecided goes to the next sweep's list; one that is also the best of its neighbourhood goes to the verify list.  In a dense
+// candidate field > 90 % of the candidates are blocked here after one or two probes.
+// List appends are aggregated per workgroup iteration (1024 candidates -> one atomic per list): device-scope atomics on a
+// single address retire at ~10 ns each on this part, so one atomic per wave (or per candidate) would dominate the sweep.
+struct BlockAppend {
+    unsigned int wave_cnt[2][4];
+    unsigned int base[2];
+};
+// each thread holds up to 4 (value, flag0, flag1) entries; appends value to list0 where flag0 and to list1 where flag1
+__device__ __forceinline__ void block_append2(BlockAppend& sh, const uint32_t (&v)[4], const bool (&f0)[4], const bool (&f1)[4],
+                                              uint32_t* __restrict__ list0, unsigned int* cnt0, uint32_t* __restrict__ list1,
+                                              unsigned int* cnt1) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned int mine[2] = {0, 0}, incl[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mine[0] += f0[k] ? 1u : 0u; mine[1] += f1[k] ? 1u : 0u; }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        incl[l] = mine[l];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(incl[l], o, 64);
+            if (lane >= o) incl[l] += t;
+        }
+        if (lane == 63) sh.wave_cnt[l][wv] = incl[l];
     }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int l = threadIdx.x;
+        const unsigned int tot = sh.wave_cnt[l][0] + sh.wave_cnt[l][1] + sh.wave_cnt[l][2] + sh.wave_cnt[l][3];
+        sh.base[l] = tot ? atomicAdd(l == 0 ? cnt0 : cnt1, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int pos0 = sh.base[0] + (incl[0] - mine[0]), pos1 = sh.base[1] + (incl[1] - mine[1]);
+    for (int w = 0; w < wv; ++w) { pos0 += sh.wave_cnt[0][w]; pos1 += sh.wave_cnt[1][w]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (f0[k]) list0[pos0++] = v[k];
+        if (f1[k]) list1[pos1++] = v[k];
+    }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void nms2d_sweep_kernel(const float* __restrict__ score, int H, int W, int r,
-                                                          const int* __restrict__ halfw, uint8_t* status,
-                                                          const uint32_t* __restrict__ list_in, uint32_t* __restrict__ list_out,
-                                                          unsigned int* cnt, uint64_t* __restrict__ keys,
-                                                          unsigned int* npicks) {
+__global__ __launch_bounds__(256) void nms2d_filter_kernel(const float* __restrict__ score, int H, int W,
+                                                           const int* __restrict__ near_cells, int n_near, const uint8_t* status,
+                                                           const uint32_t* __restrict__ list_in, uint32_t* __restrict__ list_out,
+                                                           uint32_t* __restrict__ list_ver, unsigned int* cnt, unsigned int* cnt_ver) {
+    __shared__ BlockAppend sh;
     const unsigned int n_in = cnt[0];
-    // whole waves iterate together (the appends ballot over the wave)
-    for (unsigned int base = blockIdx.x * 256; base < n_in; base += gridDim.x * 256) {
-        const unsigned int c = base + threadIdx.x;
-        bool undecided = false, selected = false;
-        uint32_t p = 0;
-        uint64_t kp = 0;
-        if (c < n_in) {
-            p = list_in[c];
-            undecided = status[p] == ST_UNDECIDED;
-        }
-        if (undecided) {
-            const int py = (int)(p / (uint32_t)W), px = (int)(p % (uint32_t)W);
-            kp = prio_key(score[p], p);
-            bool blocked = false;
-            // nearest rows first: dy = 0, -1, +1, -2, +2, ...
-            for (int k = 0; k <= 2 * r && !blocked; ++k) {
-                const int dy = (k & 1) ? -((k + 1) >> 1) : (k >> 1);
-                const int qy = py + dy;
-                if ((unsigned)qy >= (unsigned)H) continue;
-                blocked = nms2d_blocks_near(score, status, (size_t)qy * W, px, halfw[dy + r], W, dy == 0, kp);
+    for (unsigned int base = blockIdx.x * 1024; base < n_in; base += gridDim.x * 1024) {    // whole workgroups iterate together
+        uint32_t p[4];
+        bool undecided[4], survivor[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int c = base + k * 256 + threadIdx.x;
+            p[k] = 0;
+            undecided[k] = survivor[k] = false;
+            if (c < n_in) {
+                p[k] = list_in[c];
+                undecided[k] = status[p[k]] == ST_UNDECIDED;
             }
-            if (!blocked && px == 0 && py >= 1) {
-                // right-edge wrap: picks near column W-1 of rows around py-1 suppress (py, 0)
-                for (int dy = -r; dy <= r && !blocked; ++dy) {
-                    const int qy = py - 1 + dy;
-                    if ((unsigned)qy >= (unsigned)H) continue;
-                    const int hw = halfw[dy + r];
-                    if (hw >= 1) blocked = nms2d_blocks(score, status, (size_t)qy * W, max(W - hw, 0), W - 1, kp);
+            if (undecided[k]) {
+                const int py = (int)(p[k] / (uint32_t)W), px = (int)(p[k] % (uint32_t)W);
+                const uint64_t kp = prio_key(score[p[k]], p[k]);
+                bool blocked = false;
+                for (int t = 0; t < n_near && !blocked; ++t) {
+                    const int code = near_cells[t];
+                    const int qy = py + (code >> 16), qx = px + (code & 0xffff) - 32768;
+                    if ((unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W)
+                        blocked = nms_higher(score, status, (uint32_t)((size_t)qy * W + qx), kp);
                 }
-            }
-            if (!blocked) {
-                selected = true;
-                undecided = false;
-                status[p] = ST_SELECTED;
+                survivor[k] = !blocked;
             }
         }
-        keys_append(selected, kp, keys, npicks);
-        list_append(undecided, p, list_out, cnt + 1);
+        block_append2(sh, p, undecided, survivor, list_out, cnt + 1, list_ver, cnt_ver);
+    }
+}
+__global__ __launch_bounds__(256) void nms3d_filter_kernel(const float* __restrict__ score, long long n,
+                                                           const int* __restrict__ near_deltas, int n_near, const uint8_t* status,
+                                                           const uint32_t* __restrict__ list_in, uint32_t* __restrict__ list_out,
+                                                           uint32_t* __restrict__ list_ver, unsigned int* cnt, unsigned int* cnt_ver) {
+    __shared__ BlockAppend sh;
+    const unsigned int n_in = cnt[0];
+    for (unsigned int base = blockIdx.x * 1024; base < n_in; base += gridDim.x * 1024) {
+        uint32_t p[4];
+        bool undecided[4], survivor[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int c = base + k * 256 + threadIdx.x;
+            p[k] = 0;
+            undecided[k] = survivor[k] = false;
+            if (c < n_in) {
+                p[k] = list_in[c];
+                undecided[k] = status[p[k]] == ST_UNDECIDED;
+            }
+            if (undecided[k]) {
+                const uint64_t kp = prio_key(score[p[k]], p[k]);
+                bool blocked = false;
+                for (int t = 0; t < n_near && !blocked; ++t) {
+                    const long long q = (long long)p[k] + near_deltas[t];
+                    if (q >= 0 && q < n) blocked = nms_higher(score, status, (uint32_t)q, kp);
+                }
+                survivor[k] = !blocked;
+            }
+        }
+        block_append2(sh, p, undecided, survivor, list_out, cnt + 1, list_ver, cnt_ver);
     }
 }
 
-// one relaxation sweep (3-D, flat-index deltas with wrap-around; the delta set is symmetric)
-__global__ __launch_bounds__(256) void nms3d_sweep_kernel(const float* __restrict__ score, long long n,
-                                                          const int* __restrict__ deltas, int ndelta, uint8_t* status,
-                                                          const uint32_t* __restrict__ list_in, uint32_t* __restrict__ list_out,
-                                                          unsigned int* cnt, uint64_t* __restrict__ keys,
-                                                          unsigned int* npicks) {
-    const unsigned int n_in = cnt[0];
-    for (unsigned int base = blockIdx.x * 256; base < n_in; base += gridDim.x * 256) {
-        const unsigned int c = base + threadIdx.x;
-        bool undecided = false, selected = false;
-        uint32_t p = 0;
-        uint64_t kp = 0;
-        if (c < n_in) {
-            p = list_in[c];
-            undecided = status[p] == ST_UNDECIDED;
+// the (at most four) winners of a workgroup iteration: SELECTED, keys appended with one atomic for the workgroup
+__device__ __forceinline__ void winners_append(unsigned int* sh, bool won, uint32_t p, uint64_t kp, uint8_t* status,
+                                               uint64_t* __restrict__ keys, unsigned int* npicks) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = won ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int tot = sh[0] + sh[1] + sh[2] + sh[3];
+        sh[4] = tot ? atomicAdd(npicks, tot) : 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && won) {
+        unsigned int pos = sh[4];
+        for (int w = 0; w < wv; ++w) pos += sh[w];
+        status[p] = ST_SELECTED;
+        keys[pos] = kp;
+    }
+    __syncthreads();
+}
+
+// ---- sweep, phase B (one WAVE per candidate that survived phase A): the lanes stride over the whole suppressor set and
+// the wave stops at the first 64-cell slice that holds a higher-priority candidate not (yet) SUPPRESSED.  No such cell:
+// the candidate is SELECTED and its sort key goes straight to the pick list; otherwise it stays undecided (it already is
+// on the next sweep's list).
+// 2-D suppressor set of p = (py, px): the disk around p, plus -- when px == 0 and py >= 1 -- the cells (py - 1 + dy, W - dx),
+// dx >= 1, of the right-edge wrap quirk.
+__global__ __launch_bounds__(256) void nms2d_verify_kernel(const float* __restrict__ score, int H, int W,
+                                                           const int* __restrict__ cells, int ncells, uint8_t* status,
+                                                           const uint32_t* __restrict__ list_ver, const unsigned int* __restrict__ cnt_ver,
+                                                           uint64_t* __restrict__ keys, unsigned int* npicks) {
+    __shared__ unsigned int sh_win[8];
+    const unsigned int n_ver = cnt_ver[0];
+    const int lane = threadIdx.x & 63;
+    for (unsigned int i0 = blockIdx.x * 4; i0 < n_ver; i0 += gridDim.x * 4) {      // whole workgroups iterate together
+        const unsigned int i = i0 + (threadIdx.x >> 6);
+        const uint32_t p = list_ver[i < n_ver ? i : n_ver - 1];
+        const int py = (int)(p / (uint32_t)W), px = (int)(p % (uint32_t)W);
+        const uint64_t kp = prio_key(score[p], p);
+        bool blocked = i >= n_ver;                             // (a wave past the end of the list: nothing to decide)
+        for (int c0 = 0; c0 < ncells && !blocked; c0 += 64) {
+            bool hit = false;
+            const int c = c0 + lane;
+            if (c < ncells) {
+                const int code = cells[c];
+                const int qy = py + (code >> 16), qx = px + (code & 0xffff) - 32768;
+                if ((unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W && !(qy == py && qx == px))
+                    hit = nms_higher(score, status, (uint32_t)((size_t)qy * W + qx), kp);
+            }
+            blocked = __any(hit);
         }
-        if (undecided) {
-            kp = prio_key(score[p], p);
-            bool blocked = false;
-            for (int d = 0; d < ndelta && !blocked; ++d) {
+        if (!blocked && px == 0 && py >= 1) {
+            for (int c0 = 0; c0 < ncells && !blocked; c0 += 64) {
+                bool hit = false;
+                const int c = c0 + lane;
+                if (c < ncells) {
+                    const int code = cells[c];
+                    const int dy = code >> 16, dx = (code & 0xffff) - 32768;
+                    const int qy = py - 1 + dy, qx = W - dx;
+                    if (dx >= 1 && (unsigned)qy < (unsigned)H && qx >= 0)
+                        hit = nms_higher(score, status, (uint32_t)((size_t)qy * W + qx), kp);
+                }
+                blocked = __any(hit);
+            }
+        }
+        winners_append(sh_win, !blocked, p, kp, status, keys, npicks);
+    }
+}
+__global__ __launch_bounds__(256) void nms3d_verify_kernel(const float* __restrict__ score, long long n,
+                                                           const int* __restrict__ deltas, int ndelta, uint8_t* status,
+                                                           const uint32_t* __restrict__ list_ver, const unsigned int* __restrict__ cnt_ver,
+                                                           uint64_t* __restrict__ keys, unsigned int* npicks) {
+    __shared__ unsigned int sh_win[8];
+    const unsigned int n_ver = cnt_ver[0];
+    const int lane = threadIdx.x & 63;
+    for (unsigned int i0 = blockIdx.x * 4; i0 < n_ver; i0 += gridDim.x * 4) {
+        const unsigned int i = i0 + (threadIdx.x >> 6);
+        const uint32_t p = list_ver[i < n_ver ? i : n_ver - 1];
+        const uint64_t kp = prio_key(score[p], p);
+        bool blocked = i >= n_ver;
+        for (int d0 = 0; d0 < ndelta && !blocked; d0 += 64) {
+            bool hit = false;
+            const int d = d0 + lane;
+            if (d < ndelta && deltas[d] != 0) {
                 const long long q = (long long)p + deltas[d];
-                if (q < 0 || q >= n) continue;
-                blocked = nms_higher(score, status, (uint32_t)q, kp);
+                if (q >= 0 && q < n) hit = nms_higher(score, status, (uint32_t)q, kp);
             }
-            if (!blocked) {
-                selected = true;
-                undecided = false;
-                status[p] = ST_SELECTED;
-            }
+            blocked = __any(hit);
         }
-        keys_append(selected, kp, keys, npicks);
-        list_append(undecided, p, list_out, cnt + 1);
+        winners_append(sh_win, !blocked, p, kp, status, keys, npicks);
     }
 }
 
@@ -353,24 +449,30 @@ hipError_t nms_mark(const float* score, size_t n, float thr, uint8_t* status, ui
                        counters);
     return hipGetLastError();
 }
-// One sweep = pull/select over the current list (grid: a fixed number of blocks striding over the device-side list
-// length cnt[0]; `hint` bounds that length), snapshot of the pick count, push of the new picks (one wave per pick).
-// cnt[k] list lengths, snap[k] pick counts after sweep k - 1.
-hipError_t nms2d_sweep(const float* score, int H, int W, int r, const int* halfw, const int* cells, int ncells, uint8_t* status,
-                       const uint32_t* list_in, uint32_t* list_out, unsigned int* cnt, unsigned int* snap, uint64_t* keys,
-                       unsigned int* npicks, size_t hint, hipStream_t s) {
-    hipLaunchKernelGGL(nms2d_sweep_kernel, dim3(nblocks(hint, 16384)), dim3(256), 0, s, score, H, W, r, halfw, status,
-                       list_in, list_out, cnt, keys, npicks);
+// One sweep = filter (thread per candidate, near cells) -> verify (wave per survivor, whole suppressor set; selects) ->
+// snapshot of the pick count -> push (wave per new pick).  cnt[k]: length of list k (sweep k of a batch reads [k], appends
+// its leftovers under [k + 1]); cnt_ver: length of this sweep's verify list; snap[k]: picks before sweep k.
+hipError_t nms2d_sweep(const float* score, int H, int W, const int* near_cells, int n_near, const int* cells, int ncells,
+                       uint8_t* status, const uint32_t* list_in, uint32_t* list_out, uint32_t* list_ver, unsigned int* cnt,
+                       unsigned int* cnt_ver, unsigned int* snap, uint64_t* keys, unsigned int* npicks, size_t hint,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(nms2d_filter_kernel, dim3(nblocks(hint, 16384)), dim3(256), 0, s, score, H, W, near_cells, n_near, status,
+                       list_in, list_out, list_ver, cnt, cnt_ver);
+    hipLaunchKernelGGL(nms2d_verify_kernel, dim3(nblocks(hint, 8192)), dim3(256), 0, s, score, H, W, cells, ncells, status,
+                       list_ver, cnt_ver, keys, npicks);
     hipLaunchKernelGGL(nms_snap_kernel, dim3(1), dim3(1), 0, s, snap, npicks);
     hipLaunchKernelGGL(nms2d_push_kernel, dim3(nblocks(hint, 2048)), dim3(256), 0, s, score, H, W, cells, ncells, status,
                        keys, snap);
     return hipGetLastError();
 }
-hipError_t nms3d_sweep(const float* score, long long n, const int* deltas, int ndelta, uint8_t* status,
-                       const uint32_t* list_in, uint32_t* list_out, unsigned int* cnt, unsigned int* snap, uint64_t* keys,
-                       unsigned int* npicks, size_t hint, hipStream_t s) {
-    hipLaunchKernelGGL(nms3d_sweep_kernel, dim3(nblocks(hint, 16384)), dim3(256), 0, s, score, n, deltas, ndelta, status,
-                       list_in, list_out, cnt, keys, npicks);
+hipError_t nms3d_sweep(const float* score, long long n, const int* near_deltas, int n_near, const int* deltas, int ndelta,
+                       uint8_t* status, const uint32_t* list_in, uint32_t* list_out, uint32_t* list_ver, unsigned int* cnt,
+                       unsigned int* cnt_ver, unsigned int* snap, uint64_t* keys, unsigned int* npicks, size_t hint,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(nms3d_filter_kernel, dim3(nblocks(hint, 16384)), dim3(256), 0, s, score, n, near_deltas, n_near, status,
+                       list_in, list_out, list_ver, cnt, cnt_ver);
+    hipLaunchKernelGGL(nms3d_verify_kernel, dim3(nblocks(hint, 8192)), dim3(256), 0, s, score, n, deltas, ndelta, status,
+                       list_ver, cnt_ver, keys, npicks);
     hipLaunchKernelGGL(nms_snap_kernel, dim3(1), dim3(1), 0, s, snap, npicks);
     hipLaunchKernelGGL(nms3d_push_kernel, dim3(nblocks(hint, 2048)), dim3(256), 0, s, score, n, deltas, ndelta, status,
                        keys, snap);

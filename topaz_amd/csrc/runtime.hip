@@ -56,7 +56,11 @@ static const bool g_exact_fp32 = getenv("TPZ_EXACT_FP32") != nullptr;
 static const bool g_no_issuer = getenv("TPZ_NO_ISSUER") != nullptr;
 static const bool g_no_lanes = getenv("TPZ_NO_LANES") != nullptr;      // patches / tiles of an image on one stream only
 
-enum { NMS_BATCH = 4, NMS_SNAP = 8, NMS_PICKS = 15, NMS_COUNTERS = 16 };
+#ifndef TPZ_N_LANES
+#define TPZ_N_LANES 2
+#endif
+enum { N_LANES = TPZ_N_LANES };      // patch lanes: auxiliary streams the patches / tiles of an image alternate on
+enum { NMS_BATCH = 4, NMS_VER = 5, NMS_SNAP = 9, NMS_PICKS = 15, NMS_COUNTERS = 16 };
 
 struct ProfRec {
     int cls;
@@ -81,7 +85,7 @@ struct tpz_ctx {
     };
     std::vector<Buf> pool;        // workspace of the ctx stream
     std::vector<Buf>* pool_cur = &pool;
-    // Patch lanes: independent patches / tiles of one image are enqueued alternately on two auxiliary streams, each
+    // Patch lanes: independent patches / tiles of one image are enqueued round-robin on N_LANES auxiliary streams, each
     // with its own workspace pool and reduction scratch, so that the small, latency-bound launches of one patch (the
     // deep U-Net levels: 16-tile grids on 256 CUs) run under the large ones of its neighbour (lanes_begin / lane_enter /
     // lanes_end).  One host thread enqueues everything; nothing synchronises with the host.
@@ -91,7 +95,7 @@ struct tpz_ctx {
         std::vector<Buf> pool;
         double* d_part = nullptr;
     };
-    Lane lanes[2];
+    Lane lanes[N_LANES];
     struct tpz_stage* io_stage = nullptr;     // ring behind the host-pointer entry points (created on first use)
     hipEvent_t lanes_fork = nullptr;
     hipStream_t lanes_saved_stream = nullptr;
@@ -200,7 +204,7 @@ static int lanes_begin(tpz_ctx* ctx) {
 }
 static void lane_enter(tpz_ctx* ctx, int k) {
     if (!ctx->lanes_on) return;
-    tpz_ctx::Lane& ln = ctx->lanes[k & 1];
+    tpz_ctx::Lane& ln = ctx->lanes[k % N_LANES];
     ctx->stream = ln.stream;
     ctx->pool_cur = &ln.pool;
     ctx->d_part = ln.d_part;
@@ -1856,8 +1860,8 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     const int d = patch + 2 * pad;
     const size_t tn = (size_t)d * d * d;
     if (lanes_begin(ctx)) return 1;
-    const int n_lanes = ctx->lanes_on ? 2 : 1;
-    float *tiles[2] = {nullptr, nullptr}, *touts[2] = {nullptr, nullptr};
+    const int n_lanes = ctx->lanes_on ? N_LANES : 1;
+    float *tiles[N_LANES] = {}, *touts[N_LANES] = {};
     int rc = 0;
     for (int l = 0; l < n_lanes; ++l) {
         lane_enter(ctx, l);
@@ -2265,8 +2269,10 @@ int tpz_nms_2d_host(tpz_ctx* ctx, const float* h_score, int H, int W, int r, flo
 
 // ---- NMS ------------------------------------------------------------------------------------------
 // Device-side counters of one NMS call: [0 .. NMS_BATCH] lengths of the candidate lists (sweep k of a batch reads [k] and
-// appends its leftovers under [k + 1]); [NMS_SNAP + k] picks before sweep k of the batch (the push after sweep k covers
-// keys[snap[k] .. snap[k + 1])); [NMS_PICKS] picks so far.
+// appends its leftovers under [k + 1]); [NMS_VER + k] length of sweep k's verify list; [NMS_SNAP + k] picks before sweep k
+// of the batch (the push after sweep k covers keys[snap[k] .. snap[k + 1])); [NMS_PICKS] picks so far.
+// h_aux: n_aux "near" entries (phase A of a sweep) followed by n_aux2 entries of the whole suppression set (phase B, push):
+// 2-D cells dy * 65536 + (dx + 32768), 3-D flat-index deltas.
 static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int dims, int r, const int* h_aux,
                       int n_aux, int n_aux2, float threshold, int32_t* d_coords, float* d_scores, int cap, int* h_n) {
     const size_t n = (size_t)D * H * W;
@@ -2279,17 +2285,19 @@ static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, i
     uint8_t* status = (uint8_t*)pool_alloc(ctx, n);
     uint32_t* listA = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
     uint32_t* listB = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
+    uint32_t* listV = (uint32_t*)pool_alloc(ctx, n * sizeof(uint32_t));
     uint64_t* keys = (uint64_t*)pool_alloc(ctx, kcap * sizeof(uint64_t));
     int* d_aux = (int*)pool_alloc(ctx, std::max(1, n_aux + n_aux2) * sizeof(int));
     auto done = [&](int code) {
         pool_release(ctx, status);
         pool_release(ctx, listA);
         pool_release(ctx, listB);
+        pool_release(ctx, listV);
         pool_release(ctx, keys);
         pool_release(ctx, d_aux);
         return code;
     };
-    if (!status || !listA || !listB || !keys || !d_aux) return done(fail(ctx, "nms: out of device memory"));
+    if (!status || !listA || !listB || !listV || !keys || !d_aux) return done(fail(ctx, "nms: out of device memory"));
     int rc = 0;
     unsigned int* cnt = ctx->d_counters;
     prof_begin(ctx, 3, 0);
@@ -2314,10 +2322,10 @@ static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, i
     for (;;) {
         int k = 0;
         for (; k < NMS_BATCH; ++k) {
-            e = dims == 2 ? nms2d_sweep(d_score, H, W, r, d_aux, d_aux + n_aux, n_aux2, status, lin, lout, cnt + k, cnt + NMS_SNAP + k,
-                                        keys, cnt + NMS_PICKS, hint, s)
-                          : nms3d_sweep(d_score, (long long)n, d_aux, n_aux, status, lin, lout, cnt + k, cnt + NMS_SNAP + k, keys,
-                                        cnt + NMS_PICKS, hint, s);
+            e = dims == 2 ? nms2d_sweep(d_score, H, W, d_aux, n_aux, d_aux + n_aux, n_aux2, status, lin, lout, listV, cnt + k,
+                                        cnt + NMS_VER + k, cnt + NMS_SNAP + k, keys, cnt + NMS_PICKS, hint, s)
+                          : nms3d_sweep(d_score, (long long)n, d_aux, n_aux, d_aux + n_aux, n_aux2, status, lin, lout, listV, cnt + k,
+                                        cnt + NMS_VER + k, cnt + NMS_SNAP + k, keys, cnt + NMS_PICKS, hint, s);
             if (e != hipSuccess) return bail("sweep", e);
             std::swap(lin, lout);
         }
@@ -2333,7 +2341,7 @@ static int nms_common(tpz_ctx* ctx, const float* d_score, int D, int H, int W, i
         // next batch: the leftovers are list [NMS_BATCH] -> restart the chain at [0] with that length
         hint = remaining;
         e = hipMemcpyAsync(cnt, cnt + NMS_BATCH, sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipMemsetAsync(cnt + 1, 0, NMS_BATCH * sizeof(unsigned int), s);
+        if (e == hipSuccess) e = hipMemsetAsync(cnt + 1, 0, 2 * NMS_BATCH * sizeof(unsigned int), s);      // chain + verify counts
         if (e == hipSuccess) e = hipMemcpyAsync(cnt + NMS_SNAP, cnt + NMS_SNAP + NMS_BATCH, sizeof(unsigned int), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return bail("sweep chain reset", e);
     }
@@ -2358,20 +2366,22 @@ int tpz_nms_2d(tpz_ctx* ctx, const float* d_score, int H, int W, int r, float th
                float* d_scores, int cap, int* h_n) {
     if (!ctx || !d_score || H < 1 || W < 1 || r < 0) return fail(ctx, "tpz_nms_2d: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<int> halfw(2 * r + 1);
-    for (int dy = -r; dy <= r; ++dy) {
-        int hw = (int)std::floor(std::sqrt((double)(r * r - dy * dy)));
-        while ((hw + 1) * (hw + 1) + dy * dy <= r * r) ++hw;
-        while (hw * hw + dy * dy > r * r) --hw;
-        halfw[dy + r] = hw;
-    }
-    // the disk's cells for the push kernel: dy * 65536 + (dx + 32768), appended after the half widths
-    const int n_hw = (int)halfw.size();
     if (r > 16000) return fail(ctx, "tpz_nms_2d: radius too large");
+    // the suppression disk ii^2 + jj^2 <= r^2 as (dy, dx) cells, dy * 65536 + (dx + 32768); the "near" subset (phase A of a
+    // sweep) is its intersection with the 5 x 5 neighbourhood, nearest first, without the centre
+    std::vector<std::pair<int, int>> near;
+    std::vector<int> aux, full;
     for (int dy = -r; dy <= r; ++dy)
-        for (int dx = -halfw[dy + r]; dx <= halfw[dy + r]; ++dx) halfw.push_back(dy * 65536 + (dx + 32768));
-    return nms_common(ctx, d_score, 1, H, W, 2, r, halfw.data(), n_hw, (int)halfw.size() - n_hw, threshold, d_coords, d_scores,
-                      cap, h_n);
+        for (int dx = -r; dx <= r; ++dx) {
+            if (dy * dy + dx * dx > r * r) continue;
+            full.push_back(dy * 65536 + (dx + 32768));
+            if ((dy || dx) && std::abs(dy) <= 2 && std::abs(dx) <= 2) near.push_back({dy * dy + dx * dx, dy * 65536 + (dx + 32768)});
+        }
+    std::sort(near.begin(), near.end());
+    for (auto& c : near) aux.push_back(c.second);
+    const int n_near = (int)aux.size();
+    aux.insert(aux.end(), full.begin(), full.end());
+    return nms_common(ctx, d_score, 1, H, W, 2, r, aux.data(), n_near, (int)full.size(), threshold, d_coords, d_scores, cap, h_n);
 }
 
 int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, double scale, float threshold,
@@ -2383,16 +2393,26 @@ int tpz_nms_3d(tpz_ctx* ctx, const float* d_score, int D, int H, int W, int r, d
     const int width = (int)std::ceil(rr);
     const long long zs = (long long)H * W, ys = W;
     std::vector<int> deltas;
+    std::vector<std::pair<int, int>> near;
     for (int ii = -width; ii <= width; ++ii)
         for (int jj = -width; jj <= width; ++jj)
             for (int kk = -width; kk <= width; ++kk)
                 if ((double)(ii * ii + jj * jj + kk * kk) <= rr * rr) {
                     const long long dlt = ii * zs + jj * ys + kk;
-                    if (std::llabs(dlt) < ((long long)1 << 31)) deltas.push_back((int)dlt);
+                    if (std::llabs(dlt) >= ((long long)1 << 31)) continue;
+                    deltas.push_back((int)dlt);
+                    if (dlt != 0 && std::abs(ii) <= 1 && std::abs(jj) <= 1 && std::abs(kk) <= 1)
+                        near.push_back({ii * ii + jj * jj + kk * kk, (int)dlt});
                 }
     std::sort(deltas.begin(), deltas.end());
     deltas.erase(std::unique(deltas.begin(), deltas.end()), deltas.end());
-    return nms_common(ctx, d_score, D, H, W, 3, r, deltas.data(), (int)deltas.size(), 0, threshold, d_coords, d_scores, cap, h_n);
+    std::sort(near.begin(), near.end());
+    std::vector<int> aux;
+    for (auto& c : near)
+        if (std::find(aux.begin(), aux.end(), c.second) == aux.end()) aux.push_back(c.second);
+    const int n_near = (int)aux.size();
+    aux.insert(aux.end(), deltas.begin(), deltas.end());
+    return nms_common(ctx, d_score, D, H, W, 3, r, aux.data(), n_near, (int)deltas.size(), threshold, d_coords, d_scores, cap, h_n);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------
