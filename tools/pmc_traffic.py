@@ -47,11 +47,11 @@ def main():
     ap.add_argument('write_dir')
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--workload', default='pipeline')
-    ap.add_argument('--kernel', default='SplitCfg<5, 4, 128, 16, 32, 2, 8, 5>, 3, 0>', help='substring of the rocprofv3 kernel name')
+    ap.add_argument('--kernel', default=r'SplitCfg<5, 4, 128, 16, 32, 2, 8, 5(, \d+)?>, 3, 0>', help='regex on the rocprofv3 kernel name')
     ap.add_argument('--algorithmic-bytes', type=float, default=None)
     a = ap.parse_args()
-    fetch = {k: v for k, v in per_dispatch(a.fetch_dir, 'FETCH_SIZE').items() if a.kernel in k}
-    write = {k: v for k, v in per_dispatch(a.write_dir, 'WRITE_SIZE').items() if a.kernel in k}
+    fetch = {k: v for k, v in per_dispatch(a.fetch_dir, 'FETCH_SIZE').items() if re.search(a.kernel, k)}
+    write = {k: v for k, v in per_dispatch(a.write_dir, 'WRITE_SIZE').items() if re.search(a.kernel, k)}
     if not fetch or not write:
         sys.exit(f'kernel {a.kernel!r} not found in the counter files')
     name = next(iter(fetch))
