@@ -39,7 +39,12 @@ typedef struct tpz_model tpz_model;
  * the module graphs of topaz/model/features/resnet.py:243-251,185-202,
  * topaz/model/features/basic.py:98-111, topaz/model/classifier.py:64-66 and
  * topaz/denoising/models.py:130-175,515-562.                                              */
-enum { TPZ_OP_CONV = 1, TPZ_OP_MAXPOOL2 = 2 };
+enum {
+    TPZ_OP_CONV = 1,
+    TPZ_OP_MAXPOOL2 = 2,     /* MaxPool(2) with floor (the U-Net encoders, denoising/models.py:81-97) */
+    TPZ_OP_MAXPOOL = 3       /* k^dims max over a window dilated by `dil`, stride 1, no padding: the FILLED form of
+                                MaxPool(3, stride = 2) in ResNet6 and the --pooling max ResNets (resnet.py:10-47,254-339) */
+};
 
 typedef struct tpz_layer {
     int32_t op;        /* TPZ_OP_* */

@@ -403,6 +403,31 @@ def extras():
         print('cli/' + fn, os.path.getsize(os.path.join(cli_dir, fn)))
 
 
+def pooled():
+    """ResNets with MaxPool layers: ResNet6 (always pooled) and `topaz train --pooling max` ResNet8 / ResNet16
+    (resnet.py:10-47,254-339), seeded, filled; one full-module pickle for the loader."""
+    from topaz.model.classifier import LinearClassifier
+    from topaz.model.features.resnet import MaxPool, ResNet6, ResNet8, ResNet16
+    rs = np.random.RandomState(101)
+    for name, ctor, kw, bn in (('resnet6_u16', ResNet6, {}, False), ('resnet8_pool_bn_u16', ResNet8, dict(pooling=MaxPool), True),
+                               ('resnet16_pool_u8', ResNet16, dict(pooling=MaxPool), False)):
+        units = int(name.rsplit('u', 1)[1])
+        torch.manual_seed(102 + len(name))
+        m = LinearClassifier(ctor(units=units, bn=bn, **kw))
+        if bn:
+            randomise_bn(m, 103)
+        if name == 'resnet8_pool_bn_u16':
+            torch.save(m, os.path.join(OUT, 'user_model_resnet8_pool_bn_u16.sav'))      # saved unfilled, like training does
+        m.eval()
+        width = m.width
+        m.fill()
+        x = rs.randn(120, 150).astype(np.float32)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x)[None, None])[0, 0].numpy()
+        save('score_' + name, arch=np.asarray(name.split('_')[0]), pooling=np.asarray(True), width=np.asarray(width), x0=x, y0=y,
+             **sd_arrays(m))
+
+
 def downsample():
     """truncated-DFT downsample (utils/image.py:38-61), the step before the path in `topaz preprocess`"""
     from topaz.utils.image import downsample as ref_downsample

@@ -30,16 +30,28 @@ def _resid(dilation=1, stride=1):
             'dilation': 1}
 
 
-def resnet8_spec() -> List[dict]:
-    # resnet.py:293-302 with pooling=None -> stride = 2
-    s = 2
-    return [_basic(7, stride=s), _resid(dilation=2), _resid(dilation=2, stride=s), _resid(dilation=2), _basic(5)]
+def _pool():
+    # MaxPool(3, stride=2) (resnet.py:10-22)
+    return {'type': 'pool', 'k': 3, 'stride': 2, 'dilation': 1}
 
 
-def resnet16_spec() -> List[dict]:
-    # resnet.py:322-335 with pooling=None -> stride = 2
-    s = 2
-    return [_basic(7), _resid(stride=s), _resid(), _resid(), _resid(), _resid(stride=s), _resid(), _resid(), _basic(5)]
+def resnet6_spec(pooling: bool = True) -> List[dict]:
+    # resnet.py:263-273: always pooled
+    return [_basic(5), _pool(), _resid(dilation=4), _pool(), _resid(dilation=2), _basic(5)]
+
+
+def resnet8_spec(pooling: bool = False) -> List[dict]:
+    # resnet.py:291-302: stride = 2 if pooling is None else 1
+    s = 1 if pooling else 2
+    p = (lambda: [_pool()]) if pooling else (lambda: [])           # (a fresh dict per position: fill() annotates them)
+    return [_basic(7, stride=s)] + p() + [_resid(dilation=2), _resid(dilation=2, stride=s)] + p() + [_resid(dilation=2), _basic(5)]
+
+
+def resnet16_spec(pooling: bool = False) -> List[dict]:
+    # resnet.py:320-335
+    s = 1 if pooling else 2
+    p = (lambda: [_pool()]) if pooling else (lambda: [])
+    return [_basic(7), _resid(stride=s)] + p() + [_resid(), _resid(), _resid(), _resid(stride=s)] + p() + [_resid(), _resid(), _basic(5)]
 
 
 def width_of(spec: List[dict]) -> int:
@@ -60,6 +72,8 @@ def fill(spec: List[dict]) -> int:
     for m in spec:
         if m['type'] == 'basic':
             m['conv_dil'] = m['og_dilation'] * stride
+        elif m['type'] == 'pool':
+            m['pool_dil'] = stride                      # MaxPool.fill (resnet.py:30-36)
         else:
             m['conv0_fdil'] = stride
             m['conv1_fdil'] = m['conv1_dil'] * stride
@@ -85,7 +99,9 @@ def resnet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: List[dict
     h = F.pad(x, (p, p) * dims)
     for i, m in enumerate(spec):
         pre = f'{prefix}{i}.'
-        if m['type'] == 'basic':
+        if m['type'] == 'pool':
+            h = (F.max_pool3d if dims == 3 else F.max_pool2d)(h, m['k'], stride=1, dilation=m['pool_dil'])
+        elif m['type'] == 'basic':
             h = conv(h, sd[pre + 'conv.weight'], sd.get(pre + 'conv.bias'), dilation=m['conv_dil'])
             h = _bn(h, sd, pre + 'bn')
             h = F.relu(h)
@@ -135,7 +151,7 @@ def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5,
     return h
 
 
-ARCH_SPECS = {'resnet8': resnet8_spec, 'resnet16': resnet16_spec}
+ARCH_SPECS = {'resnet6': resnet6_spec, 'resnet8': resnet8_spec, 'resnet16': resnet16_spec}
 BASIC_SIZES = {'conv127': (7, 5, 5, 5, 5), 'conv63': (7, 5, 5, 5), 'conv31': (7, 5, 5)}
 
 
@@ -144,7 +160,7 @@ def to_torch_sd(sd) -> Dict[str, torch.Tensor]:
 
 
 @torch.no_grad()
-def score(arch: str, sd, x: np.ndarray, num_threads: int = 0) -> np.ndarray:
+def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = False) -> np.ndarray:
     """logits of one [H,W] image (or [D,H,W] tomogram, with 3-D weights) with the filled network `arch` (what
     extract.py:247-249 computes)."""
     if num_threads:
@@ -152,7 +168,7 @@ def score(arch: str, sd, x: np.ndarray, num_threads: int = 0) -> np.ndarray:
     sd = to_torch_sd(sd)
     xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None, None]
     if arch in ARCH_SPECS:
-        spec = ARCH_SPECS[arch]()
+        spec = ARCH_SPECS[arch](pooling) if arch != 'resnet6' else resnet6_spec()
         fill(spec)
         y = resnet_forward(xt, sd, spec)
     elif arch in BASIC_SIZES:

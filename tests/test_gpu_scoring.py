@@ -196,3 +196,36 @@ def test_scoring_3d_patches_nms_and_user_pickle(gpu_ctx):
     assert np.abs(yp - z['patched']).max() <= ATOL
     s, c = non_maximum_suppression_3d(z['y0'], int(z['nms_r']), threshold=float(z['nms_thr']))
     assert np.array_equal(c, z['nms_coords']) and np.array_equal(s, z['nms_scores'])
+
+
+# ---- ResNets with MaxPool layers: ResNet6 and `topaz train --pooling max` (resnet.py:10-47,254-339) ----------------------
+@pytest.mark.parametrize('name', ['resnet6_u16', 'resnet8_pool_bn_u16', 'resnet16_pool_u8'])
+def test_pooled_resnets_vs_reference_golden(gpu_ctx, name):
+    """filled MaxPool(3, stride 2) = a 3x3 max at the accumulated dilation, stride 1 (TPZ_OP_MAXPOOL), on fp32 planes or
+    split cells depending on its neighbours"""
+    from topaz_amd.model.classifier import LinearClassifier
+    z = load_golden(f'score_{name}')
+    m = LinearClassifier(str(z['arch']), golden_sd(z), pooling=True)
+    assert m.width == int(z['width']) and m.fill() == 4
+    y = _score(m, z['x0'])
+    assert y.shape == z['y0'].shape
+    assert np.abs(y - z['y0']).max() <= ATOL
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = _score(m, z['x0'])
+    finally:
+        gpu_ctx.set_exact(False)
+    assert np.abs(y32 - z['y0']).max() <= ATOL
+
+
+def test_pooled_resnet_user_pickle_and_larger_image(gpu_ctx):
+    import os
+    from conftest import GOLDEN
+    from topaz_amd.model.factory import load_model
+    z = load_golden('score_resnet8_pool_bn_u16')
+    m = load_model(os.path.join(GOLDEN, 'user_model_resnet8_pool_bn_u16.sav'))
+    assert m.pooling and m.arch == 'resnet8' and m.width == 77
+    assert np.abs(_score(m, z['x0']) - z['y0']).max() <= ATOL
+    x = np.random.RandomState(77).randn(333, 290).astype(np.float32)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    assert np.abs(_score(m, x) - oscoring.score('resnet8', sd, x, pooling=True)).max() <= ATOL

@@ -38,6 +38,17 @@ def test_scoring_seeded(name):
     np.testing.assert_allclose(y, z['y0'], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize('name', ['resnet6_u16', 'resnet8_pool_bn_u16', 'resnet16_pool_u8'])
+def test_scoring_pooled_resnets(name):
+    """ResNet6 and the --pooling max ResNets: filled MaxPool = dilated stride-1 max (resnet.py:30-36)"""
+    z = load_golden(f'score_{name}')
+    y = scoring.score(str(z['arch']), golden_sd(z), z['x0'], pooling=True)
+    np.testing.assert_allclose(y, z['y0'], atol=2e-5, rtol=0)
+    spec = scoring.ARCH_SPECS[str(z['arch'])](True)
+    assert scoring.width_of(spec) == int(z['width']) and scoring.fill(spec) == 4
+    assert [m['pool_dil'] for m in spec if m['type'] == 'pool'] == [1, 2]
+
+
 def test_fill_geometry():
     s8 = scoring.resnet8_spec()
     assert scoring.width_of(s8) == 71 and scoring.fill(s8) == 4

@@ -136,6 +136,12 @@ int quick(const char* name, int cin, int cout, int H) {
 
 
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "unet") {
+        bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
+        bench<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);
+        bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "stages") {
         // steps per stage (barrier every S steps), same layer, same process
         quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D2 MT64 8w S=1", 64, 64, 2048);

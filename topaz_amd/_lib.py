@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libtopaz_hip.so')
 
 TPZ_OP_CONV = 1
 TPZ_OP_MAXPOOL2 = 2
+TPZ_OP_MAXPOOL = 3
 
 
 class TpzLayer(C.Structure):

@@ -2,6 +2,9 @@
 #include "conv_registry.h"
 TPZ_CONV2D(1, 1, 64, 16, 32, 2, 1, false)
 TPZ_CONV2D(1, 1, 128, 8, 32, 4, 1, false)
+// 5x5 single-channel stems: ResNet6 (resnet.py:264)
+TPZ_CONV2D(5, 1, 32, 16, 32, 1, 5, true)
+TPZ_CONV2D(5, 1, 64, 16, 32, 1, 5, true)
 TPZ_CONV2D(7, 1, 32, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 48, 16, 32, 1, 7, true)
 TPZ_CONV2D(7, 1, 64, 16, 32, 1, 7, true)

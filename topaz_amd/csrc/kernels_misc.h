@@ -17,6 +17,8 @@ hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, 
                              hipStream_t s);
 hipError_t launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t s);
 hipError_t launch_maxpool2_split(const void* in, void* out, int C, int D, int H, int W, int dims, hipStream_t s);
+hipError_t launch_maxpoolk(const void* in, void* out, int C, int D, int H, int W, int k, int dil, int dims, bool split,
+                           hipStream_t s);
 hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, unsigned* flag,
                                hipStream_t s);
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,

@@ -196,6 +196,80 @@ __global__ __launch_bounds__(256) void maxpool2_split_kernel(const uint4* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dilated k^dims max over a window, stride 1, no padding: the FILLED form of MaxPool(3, stride = 2) in the ResNets trained
+// with --pooling max and in ResNet6 (resnet.py:10-47: fill() turns the stride into a dilation of everything downstream and
+// the pool itself into a stride-1 pool at the accumulated dilation).  fp32 planes and split cells.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpoolk_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int D,
+                                                       int H, int W, int Do, int Ho, int Wo, int k, int dil, int dims) {
+    const size_t n = (size_t)C * Do * Ho * Wo;
+    const int kz_n = dims == 3 ? k : 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        size_t t = i / Wo;
+        const int y = (int)(t % Ho);
+        t /= Ho;
+        const int z = (int)(t % Do);
+        const size_t c = t / Do;
+        const float* p = in + ((c * D + z) * H + y) * W + x;
+        float m = p[0];
+        for (int kz = 0; kz < kz_n; ++kz)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx) {
+                    const float v = p[((size_t)kz * dil * H + (size_t)ky * dil) * W + (size_t)kx * dil];
+                    m = (v > m || v != v) ? v : m;            // a NaN propagates, as in torch's max_pool
+                }
+        out[i] = m;
+    }
+}
+__global__ __launch_bounds__(256) void maxpoolk_split_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int cells,
+                                                             int D, int H, int W, int Do, int Ho, int Wo, int k, int dil,
+                                                             int dims) {
+    const size_t n = (size_t)cells * Do * Ho * Wo;
+    const size_t plane_in = (size_t)cells * D * H * W;
+    const int kz_n = dims == 3 ? k : 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % Wo);
+        size_t t = i / Wo;
+        const int y = (int)(t % Ho);
+        t /= Ho;
+        const int z = (int)(t % Do);
+        const size_t c = t / Do;
+        const size_t p = ((c * D + z) * H + y) * W + x;
+        f16x8 bh = __builtin_bit_cast(f16x8, in[p]), bl = __builtin_bit_cast(f16x8, in[plane_in + p]);
+        for (int kz = 0; kz < kz_n; ++kz)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx) {
+                    const size_t q = p + ((size_t)kz * dil * H + (size_t)ky * dil) * W + (size_t)kx * dil;
+                    const f16x8 h = __builtin_bit_cast(f16x8, in[q]), l = __builtin_bit_cast(f16x8, in[plane_in + q]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float a = (float)bh[j] + (float)bl[j], b = (float)h[j] + (float)l[j];   // the fp32 values they stand for
+                        if (b > a || b != b) { bh[j] = h[j]; bl[j] = l[j]; }
+                    }
+                }
+        out[i] = __builtin_bit_cast(uint4, bh);
+        out[n + i] = __builtin_bit_cast(uint4, bl);
+    }
+}
+hipError_t launch_maxpoolk(const void* in, void* out, int C, int D, int H, int W, int k, int dil, int dims, bool split,
+                           hipStream_t s) {
+    const int span = dil * (k - 1);
+    const int Do = dims == 3 ? D - span : 1, Ho = H - span, Wo = W - span;
+    const size_t cc = split ? split_cells(C) : (size_t)C;
+    const size_t n = cc * Do * Ho * Wo;
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+    if (split)
+        hipLaunchKernelGGL(maxpoolk_split_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, (uint4*)out, (int)cc, D, H, W,
+                           Do, Ho, Wo, k, dil, dims);
+    else
+        hipLaunchKernelGGL(maxpoolk_kernel, dim3(blocks), dim3(256), 0, s, (const float*)in, (float*)out, C, D, H, W, Do, Ho, Wo,
+                           k, dil, dims);
+    return hipGetLastError();
+}
+
 hipError_t launch_maxpool2_split(const void* in, void* out, int C, int D, int H, int W, int dims, hipStream_t s) {
     const int Do = dims == 3 ? D / 2 : 1, Ho = H / 2, Wo = W / 2;
     const size_t n = split_cells(C) * (size_t)Do * Ho * Wo;

@@ -838,7 +838,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
             const tpz_layer& Lj = m->layers[j].L;
             const bool uses = Lj.src == slot || Lj.src2 == slot || Lj.res == slot;
             if (!uses) continue;
-            if (Lj.op == TPZ_OP_MAXPOOL2) any |= slot_read_split(Lj.dst);
+            if (Lj.op == TPZ_OP_MAXPOOL2 || Lj.op == TPZ_OP_MAXPOOL) any |= slot_read_split(Lj.dst);   // pools keep the format
             else if (Lj.src2 == slot && m->layers[j].sphase.valid && m->layers[j].sphase.ki_skip_stem) continue;  // fp32
             else any |= reads[j] != 0;
         }
@@ -1465,6 +1465,26 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
                               : launch_maxpool2(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream);
             prof_end(ctx);
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
+        } else if (L.op == TPZ_OP_MAXPOOL) {
+            if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
+            const int span = L.dil * (L.k - 1);
+            const int Do = L.dims == 3 ? s1.D - span : 1, Ho = s1.H - span, Wo = s1.W - span;
+            if (Do < 1 || Ho < 1 || Wo < 1) { rc = fail(ctx, "layer %d: input too small to pool", i); break; }
+            const bool sp = s1.split && i != nl - 1;          // pooled in the format the source has
+            const float* src_p = s1.p;
+            if (s1.split && !sp) { src_p = slot_as(ctx, slots[L.src], false); if (!src_p) { rc = fail(ctx, "conversion failed"); break; } }
+            const size_t c_alloc = sp ? split_cells(s1.C) * 8 : (size_t)s1.C;
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, c_alloc * Do * Ho * Wo * sizeof(float));
+            if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
+            const int Cs = s1.C, Ds = s1.D, Hs = s1.H, Ws = s1.W;
+            set_dense(dst, p, Cs, Do, Ho, Wo);
+            dst.split = sp;
+            dst.alt = nullptr;
+            dst.owned = (i != nl - 1);
+            prof_begin(ctx, 2, 0);
+            hipError_t e = launch_maxpoolk(src_p, dst.p, Cs, Ds, Hs, Ws, L.k, L.dil, L.dims, sp, ctx->stream);
+            prof_end(ctx);
+            if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else {
             rc = fail(ctx, "layer %d: unknown op %d", i, L.op);
         }
@@ -1621,6 +1641,9 @@ int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int
             const int span = L.dil * (L.k - 1);
             s[L.dst] = {L.head ? 1 : L.cout, L.dims == 3 ? g.D + 2 * L.pad - span : 1, g.H + 2 * L.pad - span,
                         g.W + 2 * L.pad - span};
+        } else if (L.op == TPZ_OP_MAXPOOL) {
+            const int span = L.dil * (L.k - 1);
+            s[L.dst] = {g.C, L.dims == 3 ? g.D - span : 1, g.H - span, g.W - span};
         } else {
             s[L.dst] = {g.C, L.dims == 3 ? g.D / 2 : 1, g.H / 2, g.W / 2};
         }

@@ -28,8 +28,9 @@ class Features:
 
 
 class LinearClassifier:
-    def __init__(self, arch: str, state_dict, dims: Optional[int] = None):
+    def __init__(self, arch: str, state_dict, dims: Optional[int] = None, pooling: bool = False):
         self.arch = arch
+        self.pooling = bool(pooling) or arch == 'resnet6'       # MaxPool(3, stride 2) layers (resnet.py:10-47)
         self.state_dict_np = OrderedDict((k, (v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)))
                                          for k, v in state_dict.items())
         # 2-D or 3-D (classifier.py:17-29 `dims`): read off the 1x1(x1) head unless given
@@ -39,10 +40,10 @@ class LinearClassifier:
         if dims not in (2, 3) or dims != wdims:
             raise ValueError(f'LinearClassifier: dims = {dims} with {wdims}-D weights')
         self.dims = dims
-        if dims == 3 and arch not in ('resnet8', 'resnet16'):
-            raise NotImplementedError('3-D scoring is implemented for the ResNet8 / ResNet16 feature extractors')
-        if arch in ('resnet8', 'resnet16'):
-            self._program, width = pack.pack_resnet(arch, self.state_dict_np, dims)
+        if dims == 3 and arch not in ('resnet6', 'resnet8', 'resnet16'):
+            raise NotImplementedError('3-D scoring is implemented for the ResNet feature extractors')
+        if arch in ('resnet6', 'resnet8', 'resnet16'):
+            self._program, width = pack.pack_resnet(arch, self.state_dict_np, dims, self.pooling)
             units = self.state_dict_np['features.features.0.conv.weight'].shape[0]
             bn = any(k.endswith('running_mean') for k in self.state_dict_np)
         elif arch in pack.BASIC_SIZES:
@@ -80,7 +81,7 @@ class LinearClassifier:
         """LinearClassifier.fill -> ResNet.fill / BasicConv.fill: returns the total stride"""
         self.filled = True
         if self.arch.startswith('resnet'):
-            return stride * pack.resnet_fill(pack.resnet_modules(self.arch))
+            return stride * pack.resnet_fill(pack.resnet_modules(self.arch, self.pooling))
         return stride * 2 ** (len(pack.BASIC_SIZES[self.arch]) - 1)
 
     def unfill(self):

@@ -49,23 +49,30 @@ def _fold_bn(w, b, sd, bn_prefix):
     return w2.astype(np.float32), b2.astype(np.float32)
 
 
-# ---- ResNet8 / ResNet16 ---------------------------------------------------------------------------
-def resnet_modules(arch: str) -> List[dict]:
-    """module list of make_modules with pooling=None (stride 2 where the reference strides)"""
+# ---- ResNet6 / ResNet8 / ResNet16 -------------------------------------------------------------------
+def resnet_modules(arch: str, pooling: bool = False) -> List[dict]:
+    """module list of make_modules (resnet.py:254-339).  pooling=False: the convolutions stride where the reference strides
+    (`stride = 2 if pooling is None else 1`); pooling=True (`topaz train --pooling max`): stride-1 convolutions and a
+    MaxPool(3, stride 2) after the strided positions.  ResNet6 always pools."""
     B = lambda k, s=1: dict(kind='basic', k=k, stride=s, og_dil=1)
     R = lambda d=1, s=1: dict(kind='resid', d=d, stride=s)
-    if arch == 'resnet8':       # resnet.py:293-302
-        return [B(7, 2), R(2), R(2, 2), R(2), B(5)]
-    if arch == 'resnet16':      # resnet.py:322-335
-        return [B(7), R(1, 2), R(), R(), R(), R(1, 2), R(), R(), B(5)]
+    P = lambda: dict(kind='pool', k=3, stride=2)
+    s = 1 if pooling else 2
+    pool = (lambda: [P()]) if pooling else (lambda: [])         # a fresh dict per position: resnet_fill annotates them
+    if arch == 'resnet6':       # resnet.py:254-277
+        return [B(5), P(), R(4), P(), R(2), B(5)]
+    if arch == 'resnet8':       # resnet.py:280-306
+        return [B(7, s)] + pool() + [R(2), R(2, s)] + pool() + [R(2), B(5)]
+    if arch == 'resnet16':      # resnet.py:309-339
+        return [B(7), R(1, s)] + pool() + [R(), R(), R(), R(1, s)] + pool() + [R(), R(), B(5)]
     raise ValueError(f'unknown ResNet architecture {arch!r}')
 
 
 def resnet_width(mods: Sequence[dict]) -> int:
-    """insize_from_outsize(modules, 1) (model/utils.py:39-68): ResidA reports kernel 2*d+3, dilation 1"""
+    """insize_from_outsize(modules, 1) (model/utils.py:39-68): ResidA reports kernel 2*d+3, dilation 1; MaxPool kernel 3"""
     out = 1
     for m in reversed(mods):
-        k = m['k'] if m['kind'] == 'basic' else 2 * m['d'] + 3
+        k = m['k'] if m['kind'] in ('basic', 'pool') else 2 * m['d'] + 3
         out = (out - 1) * m['stride'] + 1 + (k - 1)
     return out
 
@@ -76,16 +83,18 @@ def resnet_fill(mods: Sequence[dict]) -> int:
     for m in mods:
         if m['kind'] == 'basic':
             m['dil'] = m['og_dil'] * stride            # BasicConv.fill, resnet.py:87-92
+        elif m['kind'] == 'pool':
+            m['dil'] = stride                          # MaxPool.fill, resnet.py:30-36
         else:
             m['dil0'], m['dil1'] = stride, m['d'] * stride   # ResidA.fill, resnet.py:153-164
         stride *= m['stride']
     return stride
 
 
-def pack_resnet(arch: str, sd, dims: int = 2) -> Tuple[LayerProgram, int]:
+def pack_resnet(arch: str, sd, dims: int = 2, pooling: bool = False) -> Tuple[LayerProgram, int]:
     """dims = 3: the same graph over Conv3d / BatchNorm3d weights (resnet.py:56-63,115-123; `--dims 3`)"""
     sd = _np(sd)
-    mods = resnet_modules(arch)
+    mods = resnet_modules(arch, pooling)
     width = resnet_width(mods)
     resnet_fill(mods)
     if sd['features.features.0.conv.weight'].ndim != dims + 2:
@@ -99,7 +108,9 @@ def pack_resnet(arch: str, sd, dims: int = 2) -> Tuple[LayerProgram, int]:
         pre = f'{pre0}{i}.'
         last = i == len(mods) - 1
         pad = width // 2 if i == 0 else 0            # F.pad(x, width//2) once, then valid convs (resnet.py:246-249)
-        if m['kind'] == 'basic':
+        if m['kind'] == 'pool':
+            cur = P.maxpool(cur, m['k'], m['dil'])     # parameter-free, but it owns index i of features.features
+        elif m['kind'] == 'basic':
             w, b = _fold_bn(sd[pre + 'conv.weight'], sd.get(pre + 'conv.bias'), sd, pre + 'bn')
             kw = dict(head_w=head_w, head_b=head_b) if last else {}
             cur = P.conv(cur, w, b, dil=m['dil'], pad=pad, slope=0.0, **kw)

@@ -105,7 +105,9 @@ def _walk(mod, prefix, out):
             _walk(m, prefix + k + '.', out)
 
 
-def load_module_pickle(path) -> Tuple[str, 'OrderedDict[str, torch.Tensor]']:
+def load_module_pickle(path, with_pooling: bool = False):
+    """(arch, state_dict) of a pickled LinearClassifier; with_pooling=True adds whether the feature stack holds MaxPool
+    layers (`topaz train --pooling max`, ResNet6)."""
     obj = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_PickleModule)
     if isinstance(obj, (dict, OrderedDict)) and all(torch.is_tensor(v) for v in obj.values()):
         raise ValueError(f'{path} holds a bare state_dict; the architecture cannot be inferred. '
@@ -118,12 +120,17 @@ def load_module_pickle(path) -> Tuple[str, 'OrderedDict[str, torch.Tensor]']:
     fname = fq.rsplit('.', 1)[-1]
     sd = OrderedDict()
     _walk(obj, '', sd)
-    if fname in ('ResNet8', 'ResNet16'):
+    pooling = False
+    if fname in ('ResNet6', 'ResNet8', 'ResNet16'):
         arch = fname.lower()
-        # pooling / ResNet6 variants change the graph; they are not on the hot path
         mods = feats.__dict__['_modules']['features'].__dict__['_modules']
-        if any(type(m).__name__ == 'MaxPool' for m in mods.values()):
-            raise NotImplementedError(f'{path}: ResNet with pooling layers is not supported on the MI355X path')
+        kinds = [type(m).__name__ for m in mods.values()]
+        pooling = 'MaxPool' in kinds
+        if any(k not in ('BasicConv', 'ResidA', 'MaxPool', 'Dropout') for k in kinds):
+            raise NotImplementedError(f'{path}: {arch} with layers {sorted(set(kinds))} is not supported on the MI355X path')
+        if 'Dropout' in kinds:
+            # nn.Dropout modules shift the indices of features.features; inference ignores them
+            raise NotImplementedError(f'{path}: models trained with --dropout > 0 are not supported yet')
     elif fname in ('BasicConv', 'Conv127', 'Conv63', 'Conv31'):
         n_convs = sum(1 for k, v in sd.items() if k.startswith('features.features.') and v.dim() == 4)
         arch = {5: 'conv127', 4: 'conv63', 3: 'conv31'}.get(n_convs)
@@ -131,4 +138,4 @@ def load_module_pickle(path) -> Tuple[str, 'OrderedDict[str, torch.Tensor]']:
             raise ValueError(f'{path}: BasicConv with {n_convs} convolutions is not a conv127/63/31 stack')
     else:
         raise NotImplementedError(f'{path}: feature extractor {fname} is not supported on the MI355X path')
-    return arch, sd
+    return (arch, sd, pooling) if with_pooling else (arch, sd)

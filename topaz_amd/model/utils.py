@@ -1,11 +1,10 @@
 """Mirror of the patching helpers of topaz/model/utils.py: insize_from_outsize (:39-68),
 predict_in_patches (:110-130), get_patches (:133-169), reconstruct_from_patches (:172-193).
 
-Patch geometry is host logic; each patch is scored by the HIP model on the device and only the
-cropped scores come back.  Quirk kept from the reference: all-zero tiles are skipped by
-get_patches (:159,165) while reconstruct_from_patches (:181-191) does not know about it, so an
-image with an all-zero tile desynchronises the stitching (IndexError or shifted tiles) exactly as
-upstream does.
+Patch geometry is host logic; predict_in_patches keeps the image, the tiles and the stitched map on the device
+(one upload, one download).  Quirk kept from the reference: all-zero tiles are skipped by get_patches (:159,165)
+while reconstruct_from_patches (:181-191) does not know about it, so an image with an all-zero tile ends in
+IndexError exactly as upstream does.
 """
 from __future__ import annotations
 
@@ -74,16 +73,40 @@ def reconstruct_from_patches(patches, original_shape, patch_size, patch_padding=
 
 
 def predict_in_patches(model, X: torch.Tensor, patch_size: int, is_3d: bool = False, use_cuda: bool = True) -> np.ndarray:
-    """X: [1,1,H,W] host or device tensor.  The model pads each patch again (filled mode), the
-    scores are cropped by width//2 and stitched (model/utils.py:110-130)."""
+    """X: [1,1,(D,)H,W] host or device tensor -> float64 array of the same shape (model/utils.py:110-130): tiles of
+    `patch_size` cut from the image padded by width // 2 at stride patch_size - 2 * (width // 2); the filled model pads each
+    tile again, its scores are cropped by width // 2 and stitched.
+    The image goes to the device ONCE; tiles are device views, the stitched map is assembled on the device and comes back in
+    one copy (upstream moves every tile on and off the GPU).  The all-zero-tile quirk is kept: get_patches skips such tiles
+    (:159,165) while reconstruct_from_patches does not know about it and runs out of tiles -- the same IndexError here."""
     pad = model.width // 2
-    patches = get_patches(X, patch_size, patch_padding=pad, is_3d=is_3d)
-    scores = []
-    for patch in patches:
+    dims = 3 if is_3d else 2
+    dev = model.device_model.ctx.torch_device()
+    x = X.to(device=dev, dtype=torch.float32)
+    padded = torch.nn.functional.pad(x, (pad, pad) * dims)
+    shape = tuple(x.shape[-dims:])
+    step = patch_size - 2 * pad
+    if step <= 0:
+        raise ValueError(f'patch_size {patch_size} does not exceed the receptive field {model.width}')
+    starts = [(i, j, k) for i in range(0, shape[-2], step) for j in range(0, shape[-1], step)
+              for k in (range(0, shape[-3], step) if is_3d else (None,))]
+    scored = []
+    for (i, j, k) in starts:
+        tile = padded[..., i:i + patch_size, j:j + patch_size] if k is None else \
+            padded[..., k:k + patch_size, i:i + patch_size, j:j + patch_size]
+        if float(tile.abs().sum()) == 0:
+            continue                                       # get_patches drops all-zero tiles
         with torch.no_grad():
-            s = model(patch.cuda() if not patch.is_cuda else patch)[0, 0].cpu().numpy()
+            s = model(tile.contiguous())[0, 0]
         s = s[..., pad:-pad, pad:-pad]
-        if is_3d:
-            s = s[..., pad:-pad, :, :]
-        scores.append(s)
-    return reconstruct_from_patches(scores, X.shape, patch_size, patch_padding=pad, is_3d=is_3d)
+        scored.append(s[pad:-pad] if is_3d else s)
+    if len(scored) < len(starts):
+        # upstream stitches patches[idx] for every slot of the grid and runs past the end of the kept tiles
+        raise IndexError('list index out of range (an all-zero tile was skipped: topaz/model/utils.py:159,181-191)')
+    out = torch.zeros(tuple(X.shape), dtype=torch.float64, device=dev)
+    for (i, j, k), s in zip(starts, scored):
+        if k is None:
+            out[..., i:i + s.shape[-2], j:j + s.shape[-1]] = s
+        else:
+            out[..., k:k + s.shape[-3], i:i + s.shape[-2], j:j + s.shape[-1]] = s
+    return out.cpu().numpy()

@@ -299,6 +299,19 @@ class LayerProgram:
         self.layers.append(L)
         return L.dst
 
+    def maxpool(self, src: int, k: int = 3, dil: int = 1) -> int:
+        """k^dims max over a window dilated by `dil`, stride 1, no padding (TPZ_OP_MAXPOOL: a filled MaxPool(k, stride))"""
+        L = TpzLayer()
+        L.op = _lib.TPZ_OP_MAXPOOL
+        L.dims = self.dims
+        L.src, L.src2, L.res = src, -1, -1
+        L.dst = self.new_slot()
+        L.k, L.dil, L.pad = k, dil, 0
+        L.w_off = L.b_off = L.post_scale_off = L.post_shift_off = L.head_w_off = L.head_b_off = -1
+        L.slope = 1.0
+        self.layers.append(L)
+        return L.dst
+
     def flat_blob(self) -> np.ndarray:
         if not self.blob:
             return np.zeros(1, dtype=np.float32)
