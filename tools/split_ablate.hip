@@ -136,6 +136,12 @@ int quick(const char* name, int cin, int cout, int H) {
 
 
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "proj") {
+        // 1x1 projection 64 -> 128 at 4136^2 (ResidA.proj): tile shapes, same process
+        quick<SplitCfg<1, 1, 128, 16, 16, 4, 8, 1, 1>, EPI_PLAIN>("K1 MT128 8w 16x16 CC4 (current)", 64, 128, 4136);
+        quick<SplitCfg<1, 1, 128, 8, 16, 4, 4, 1, 1>, EPI_PLAIN>("K1 MT128 4w 8x16 CC4", 64, 128, 4136);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "unet") {
         bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
         bench<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);

@@ -238,8 +238,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
     }
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
-    auto compute_offsets = [&](bool second) {
-        const int Hs = second ? a.Hin : a.H1, Ws = second ? a.Win : a.W1;
+    // (tid and the sizes nearest_src() divides are passed in: the co-group loop hands over opaque copies, so that nothing of this prologue is
+    // hoisted out of that loop and kept in registers across the K loop)
+    auto compute_offsets = [&](bool second, int tid, int H1, int W1, int Hup, int Wup) {
+        const int Hs = second ? a.Hin : H1, Ws = second ? a.Win : W1;
 #pragma unroll 1
         for (int i = 0; i < C::NR; ++i) {
             const int g = i * C::THREADS + tid;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 unsigned off = OOB;
                 if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) {
                     int sy = gy, sx = gx;
-                    if (!second && ups) { sy = nearest_src(gy, a.H1, a.Hin); sx = nearest_src(gx, a.W1, a.Win); }
+                    if (!second && ups) { sy = nearest_src(gy, H1, Hup); sx = nearest_src(gx, W1, Wup); }
                     // 3-D: the in-plane part only; the (cell, plane) part is added per chunk in issue_input
                     off = vol ? (unsigned)(((size_t)sy * Ws + sx) * 16) : (unsigned)((((size_t)c * Hs + sy) * Ws + sx) * 16);
                 }
@@ -350,15 +352,21 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         __syncthreads();                       // slot table written / previous co-group done with the buffers
-        compute_offsets(chunks1 == 0);
+        // the prologue of a co-group works from opaque copies of the thread id and the source size: its lane-dependent
+        // values are then computed here and die here, instead of being hoisted out of this loop and spilled across the
+        // K loop of the fused-head variant (which runs two co-groups per tile at 256 VGPRs)
+        int tid_p = tid, H1_p = a.H1, W1_p = a.W1, Hup_p = a.Hin, Wup_p = a.Win;
+        asm volatile("" : "+v"(tid_p), "+s"(H1_p), "+s"(W1_p), "+s"(Hup_p), "+s"(Wup_p));
+        const int wave_p = __builtin_amdgcn_readfirstlane(tid_p >> 6), l4_p = (tid_p & 63) >> 4;
+        compute_offsets(chunks1 == 0, tid_p, H1_p, W1_p, Hup_p, Wup_p);
 #pragma unroll 1
-        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r, tid, wave);
-        issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid, wave);
+        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r, tid_p, wave_p);
+        issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid_p, wave_p);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // LDS address of this lane's B fragments of step st (its slot of the step: tap + cell of the chunk's tile)
-        auto b_frag_base = [&](int st) -> const unsigned char* {
+        auto b_frag_base = [&](int st, int l4) -> const unsigned char* {
             if constexpr (C::CONT) {
                 int G = 4 * st + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
                 if (cg2 >= n_full) {
@@ -381,14 +389,15 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         f16x8 bh[NW], bo[NW], ah[2], ao[2];
         auto b_off = [&](int n) { return ((n / NFC) * C::ITW + (n % NFC) * 16) * 16; };
         {
-            const unsigned char* bl = b_frag_base(0);
+            const unsigned char* bl = b_frag_base(0, l4_p);
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 bh[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n));
                 bo[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n) + C::PLANE_BYTES);
             }
-            ah[0] = *reinterpret_cast<const f16x8*>(lds + a_lane);
-            ao[0] = *reinterpret_cast<const f16x8*>(lds + a_lane + MW * 1024);
+            const unsigned a_lane_p = (unsigned)(C::OFF_W + (tid_p & 63) * 16);
+            ah[0] = *reinterpret_cast<const f16x8*>(lds + a_lane_p);
+            ao[0] = *reinterpret_cast<const f16x8*>(lds + a_lane_p + MW * 1024);
         }
 
 #pragma unroll 1
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     }
                 }
                 if (!(ABL & 256) && pf < a.n_chunks && r0 < C::NR) {
-                    if (r0 == 0 && pf == chunks1) compute_offsets(true);         // switching to the second source
+                    if (r0 == 0 && pf == chunks1) compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win);         // switching to the second source
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
 #pragma unroll 1
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             //   B fragments and A(0) of step s + 1.  The matrix core is not left idle for an LDS round trip after every
             //   barrier (150 - 250 cycles of a step of 768 (MT = 64) ... 3072 (MT = 128, 8 waves) cycles).
             //   MFMA order within a channel fragment: ah*bo, ah*bh, ao*bh -- the lo halves of B are released first.
-            const unsigned char* bl_next = b_frag_base(s + 1 < n_stages ? s + 1 : s);      // (slot-table lookup: early)
+            const unsigned char* bl_next = b_frag_base(s + 1 < n_stages ? s + 1 : s, l4);      // (slot-table lookup: early)
             const unsigned char* al = lds + a_lane + (stage & 1) * C::W_STAGE_BYTES + sub * C::W_STEP_BYTES;
             const int stage_n = (s + 1) / C::SPS;
             const unsigned char* al_next = lds + a_lane + (stage_n & 1) * C::W_STAGE_BYTES + (s + 1 - stage_n * C::SPS) * C::W_STEP_BYTES;

@@ -6,4 +6,4 @@ TPZ_SPLIT4_RESID(3, 1, 32, 8, 32, 2)
 TPZ_SPLIT4_RESID(3, 2, 32, 8, 32, 2)
 TPZ_SPLIT4_RESID(3, 4, 32, 8, 32, 2)
 TPZ_SPLIT_RESID_S(3, 8, 64, 16, 32, 2, 2)
-TPZ_SPLIT(1, 1, 64, 16, 16, 4, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4(1, 1, 64, 8, 16, 4, ::tpz::EPI_PLAIN)
