@@ -428,6 +428,30 @@ def pooled():
              **sd_arrays(m))
 
 
+def dropout():
+    """`topaz train --dropout p` models: nn.Dropout modules sit between the blocks (resnet.py:296-303, basic.py:57-70) and
+    shift the indices of every later module; inference ignores them.  Full-module pickles (saved unfilled, as training
+    does) + the reference's own eval-mode scores of the filled nets."""
+    from topaz.model.classifier import LinearClassifier
+    from topaz.model.features.basic import BasicConv
+    from topaz.model.features.resnet import ResNet8
+    rs = np.random.RandomState(131)
+    out = {}
+    for name, make in (('resnet8_drop_bn_u16', lambda: ResNet8(units=16, bn=True, dropout=0.25)),
+                       ('conv31_drop_bn_u16', lambda: BasicConv(layers=[7, 5, 5], units=16, bn=True, dropout=0.3))):
+        torch.manual_seed(132 + len(name))
+        m = LinearClassifier(make())
+        randomise_bn(m, 133)
+        torch.save(m, os.path.join(OUT, f'user_model_{name}.sav'))
+        m.eval()
+        m.fill()
+        x = rs.randn(96, 130).astype(np.float32)
+        with torch.no_grad():
+            out[name + ':x'] = x
+            out[name + ':y'] = m(torch.from_numpy(x)[None, None])[0, 0].numpy()
+    save('score_dropout_models', **out)
+
+
 def downsample():
     """truncated-DFT downsample (utils/image.py:38-61), the step before the path in `topaz preprocess`"""
     from topaz.utils.image import downsample as ref_downsample

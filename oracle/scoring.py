@@ -40,18 +40,28 @@ def resnet6_spec(pooling: bool = True) -> List[dict]:
     return [_basic(5), _pool(), _resid(dilation=4), _pool(), _resid(dilation=2), _basic(5)]
 
 
-def resnet8_spec(pooling: bool = False) -> List[dict]:
-    # resnet.py:291-302: stride = 2 if pooling is None else 1
+def _drop():
+    # nn.Dropout(p) of `topaz train --dropout p` (resnet.py:296,300,303 / 326,332,336): identity at inference, but it
+    # takes an index in features.features
+    return {'type': 'drop'}
+
+
+def resnet8_spec(pooling: bool = False, dropout: bool = False) -> List[dict]:
+    # resnet.py:291-303: stride = 2 if pooling is None else 1
     s = 1 if pooling else 2
     p = (lambda: [_pool()]) if pooling else (lambda: [])           # (a fresh dict per position: fill() annotates them)
-    return [_basic(7, stride=s)] + p() + [_resid(dilation=2), _resid(dilation=2, stride=s)] + p() + [_resid(dilation=2), _basic(5)]
+    d = [_drop()] if dropout else []
+    return ([_basic(7, stride=s)] + p() + d + [_resid(dilation=2), _resid(dilation=2, stride=s)] + p() + d +
+            [_resid(dilation=2), _basic(5)] + d)
 
 
-def resnet16_spec(pooling: bool = False) -> List[dict]:
-    # resnet.py:320-335
+def resnet16_spec(pooling: bool = False, dropout: bool = False) -> List[dict]:
+    # resnet.py:320-336
     s = 1 if pooling else 2
     p = (lambda: [_pool()]) if pooling else (lambda: [])
-    return [_basic(7), _resid(stride=s)] + p() + [_resid(), _resid(), _resid(), _resid(stride=s)] + p() + [_resid(), _resid(), _basic(5)]
+    d = [_drop()] if dropout else []
+    return ([_basic(7), _resid(stride=s)] + p() + d + [_resid(), _resid(), _resid(), _resid(stride=s)] + p() + d +
+            [_resid(), _resid(), _basic(5)] + d)
 
 
 def width_of(spec: List[dict]) -> int:
@@ -60,6 +70,8 @@ def width_of(spec: List[dict]) -> int:
     (resnet.py:73-78) and ResidA (resnet.py:138-141: kernel_size = 2*dilation+3, dilation = 1)."""
     out = 1
     for m in spec[::-1]:
+        if m['type'] == 'drop':
+            continue
         dil = m['dilation'] if m['type'] == 'basic' else 1
         out = (out - 1) * m['stride'] + 1 + (m['k'] - 1) * dil
     return out
@@ -70,6 +82,8 @@ def fill(spec: List[dict]) -> int:
     strides into dilations (BasicConv.fill :87-92, ResidA.fill :153-164).  Returns the total stride."""
     stride = 1
     for m in spec:
+        if m['type'] == 'drop':
+            continue
         if m['type'] == 'basic':
             m['conv_dil'] = m['og_dilation'] * stride
         elif m['type'] == 'pool':
@@ -99,6 +113,8 @@ def resnet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: List[dict
     h = F.pad(x, (p, p) * dims)
     for i, m in enumerate(spec):
         pre = f'{prefix}{i}.'
+        if m['type'] == 'drop':
+            continue
         if m['type'] == 'pool':
             h = (F.max_pool3d if dims == 3 else F.max_pool2d)(h, m['k'], stride=1, dilation=m['pool_dil'])
         elif m['type'] == 'basic':
@@ -124,7 +140,7 @@ def resnet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], spec: List[dict
 
 
 def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5, 5, 5, 5),
-                      prefix='features.features.', head=True) -> torch.Tensor:
+                      prefix='features.features.', head=True, dropout=False) -> torch.Tensor:
     """Filled forward of LinearClassifier(basic.BasicConv(sizes, units)) -- conv127/63/31
     (basic.py:12-111, factory.py:15-25).  Every conv but the last has stride 2 (no pooling), so
     fill() gives dilations 1,2,4,... (basic.py:81-89); pad = width//2 with width from the strided
@@ -136,16 +152,27 @@ def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5,
         width = (width - 1) * s + 1 + (k - 1)
     p = width // 2
     h = F.pad(x, (p, p, p, p))
-    idx, dil = 0, 1
-    for k, s in zip(sizes, strides):
+    # fill() zips the layers with `strides`, which has no entry for Dropout layers (basic.py:57-58,69-70,81-89): a model
+    # built with dropout > 0 gets the dilations this slipped walk gives (conv31: 1,4,4), any other 1,2,4,...
+    kinds, zs = [], []
+    for st in strides:
+        kinds += ['conv'] + (['bn'] if has_bn else []) + ['act'] + (['drop'] if dropout else [])
+        zs += [st] + ([1] if has_bn else []) + [1]
+    dils, cum = [], 1
+    for kind, st in zip(kinds, zs):
+        if kind == 'conv':
+            dils.append(cum)
+        cum *= st
+    dils += [1] * (len(sizes) - len(dils))
+    idx = 0
+    for dil in dils:
         h = F.conv2d(h, sd[f'{prefix}{idx}.weight'], sd.get(f'{prefix}{idx}.bias'), dilation=dil)
         idx += 1
         if has_bn:
             h = _bn(h, sd, f'{prefix}{idx}')
             idx += 1
         h = F.prelu(h, sd[f'{prefix}{idx}.weight'])
-        idx += 1
-        dil *= s
+        idx += 1 + (1 if dropout else 0)              # (Dropout: identity in eval mode)
     if head:
         h = F.conv2d(h, sd['classifier.weight'], sd['classifier.bias'])
     return h
@@ -160,19 +187,20 @@ def to_torch_sd(sd) -> Dict[str, torch.Tensor]:
 
 
 @torch.no_grad()
-def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = False) -> np.ndarray:
+def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = False, dropout: bool = False) -> np.ndarray:
     """logits of one [H,W] image (or [D,H,W] tomogram, with 3-D weights) with the filled network `arch` (what
-    extract.py:247-249 computes)."""
+    extract.py:247-249 computes).  dropout=True: `sd` is the state_dict of a model built with dropout > 0 (upstream's
+    numbering, Dropout modules included)."""
     if num_threads:
         torch.set_num_threads(num_threads)
     sd = to_torch_sd(sd)
     xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None, None]
     if arch in ARCH_SPECS:
-        spec = ARCH_SPECS[arch](pooling) if arch != 'resnet6' else resnet6_spec()
+        spec = ARCH_SPECS[arch](pooling, dropout) if arch != 'resnet6' else resnet6_spec()
         fill(spec)
         y = resnet_forward(xt, sd, spec)
     elif arch in BASIC_SIZES:
-        y = basicconv_forward(xt, sd, BASIC_SIZES[arch])
+        y = basicconv_forward(xt, sd, BASIC_SIZES[arch], dropout=dropout)
     else:
         raise ValueError(arch)
     return y[0, 0].numpy()

@@ -104,6 +104,35 @@ def test_user_model_pickle_parses_without_reference(name, arch):
         assert np.array_equal(sd[k].numpy(), want[k]), k
 
 
+def test_dropout_pickles_are_renumbered_and_basicconv_fill_slips():
+    """models trained with --dropout: the unpickler drops the nn.Dropout indices; the packer reproduces upstream's fill()
+    of such a BasicConv (basic.py:57-89) -- and the oracle, run on upstream's numbering, matches the reference's scores"""
+    from oracle import scoring
+    from topaz_amd.model import pack
+    from topaz_amd.model.unpickle import load_module_pickle
+    assert pack.basic_fill_dilations(3, True, False) == [1, 2, 4]
+    assert pack.basic_fill_dilations(5, False, False) == [1, 2, 4, 8, 16]
+    assert pack.basic_fill_dilations(3, True, True) == [1, 4, 4]
+    z = load_golden('score_dropout_models')
+    for name, arch in (('resnet8_drop_bn_u16', 'resnet8'), ('conv31_drop_bn_u16', 'conv31')):
+        a, sd, traits = load_module_pickle(os.path.join(GOLDEN, f'user_model_{name}.sav'), with_traits=True)
+        assert a == arch and traits == {'pooling': False, 'dropout': True}
+        idx = sorted({int(k.split('.')[2]) for k in sd if k.startswith('features.features.')})
+        assert idx == list(range(len(idx)))                       # contiguous: no holes where the Dropouts were
+        # upstream's numbering back again -> the oracle's dropout=True walk
+        kinds = {'resnet8': 'BDRRDRBD', 'conv31': 'CNADCNADCNAD'}[arch]
+        keep = [i for i, c in enumerate(kinds) if c != 'D']
+        raw = {}
+        for k, v in sd.items():
+            if k.startswith('features.features.'):
+                parts = k.split('.')
+                parts[2] = str(keep[int(parts[2])])
+                k = '.'.join(parts)
+            raw[k] = v.numpy()
+        y = scoring.score(arch, raw, z[name + ':x'], dropout=True)
+        assert np.abs(y - z[name + ':y']).max() < 3e-5
+
+
 def test_patch_geometry_helpers():
     import torch
     from topaz_amd.model.utils import get_patches, reconstruct_from_patches, insize_from_outsize

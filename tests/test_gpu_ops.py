@@ -170,6 +170,29 @@ def test_filter_2d_gaussian(gpu_ctx):
     _close(rt.filter_2d(x, f), ref, atol=1e-5)
 
 
+def test_gaussian_3d_volume_vs_conv3d(gpu_ctx):
+    """GaussianDenoise(sigma, dims=3).apply: the Conv3d(1,1,width,padding=width//2) of filters.py:55-80 -- checked against
+    torch's conv3d with the full (non-separated) normalised kernel, fp64 reference"""
+    from topaz_amd.filters import GaussianDenoise, gaussian_filter
+    g = GaussianDenoise(0.9, dims=3)
+    w = gaussian_filter(0.9, s=g.weight.shape[-1], dims=3)
+    w /= w.sum()
+    assert g.weight.shape == w.shape and np.allclose(g.weight, w.astype(np.float32))
+    x = np.random.default_rng(5).standard_normal((13, 21, 34)).astype(np.float32)
+    ref = F.conv3d(torch.from_numpy(x).double()[None, None], torch.from_numpy(w)[None, None], padding=w.shape[0] // 2)[0, 0]
+    y = g.apply(x)
+    assert y.shape == x.shape and y.dtype == np.float32
+    assert np.abs(y - ref.numpy()).max() < 1e-5
+
+
+def test_denoise3d_gaussian_flag_fails_like_upstream(gpu_ctx, tmp_path):
+    """upstream: GaussianDenoise(gaus) is 2-D (denoise.py:546) and meets a volume at :509 -> Conv2d raises before any
+    file is written"""
+    from topaz_amd.denoise import denoise_tomogram_stream
+    with pytest.raises(RuntimeError):
+        denoise_tomogram_stream([str(tmp_path / 'none.mrc')], None, str(tmp_path), gaus=1.0)
+
+
 CONV3D_CASES = [
     # cin, cout, k, pad, D, H, W, slope
     (1, 48, 7, 3, 20, 22, 40, 0.1),        # CIN1 3-D stem

@@ -104,6 +104,20 @@ def test_user_model_pickle(gpu_ctx, name):
     assert np.abs(_score(m, z['x0']) - z['y0']).max() <= ATOL
 
 
+@pytest.mark.parametrize('name', ['resnet8_drop_bn_u16', 'conv31_drop_bn_u16'])
+def test_user_model_trained_with_dropout(gpu_ctx, name):
+    """`topaz train --dropout p` pickles: nn.Dropout modules shift the module indices (resnet.py:296-303) and, in BasicConv,
+    make fill() slip (basic.py:57-89: conv31 is scored with dilations 1,4,4) -- the golden is what the reference's own
+    filled, eval-mode model returned"""
+    import os
+    from conftest import GOLDEN
+    from topaz_amd.model.factory import load_model
+    z = load_golden('score_dropout_models')
+    m = load_model(os.path.join(GOLDEN, f'user_model_{name}.sav'))
+    assert m.dropout
+    assert np.abs(_score(m, z[name + ':x']) - z[name + ':y']).max() <= ATOL
+
+
 def test_full_size_4096_windows_vs_oracle(gpu_ctx):
     """BASELINE size (4096x4096): the filled net is translation equivariant with a 71-pixel receptive
     field, so any window of the full-size score map must equal the oracle run on the window's own

@@ -28,6 +28,7 @@ float run(const SplitArgs& a, dim3 grid, int iters) {
     return ms / iters;
 }
 
+static bool g_lat = false;
 template <class C, int EPI>
 int bench(const char* name, int cin, int cout, int H) {
     const int span = C::D * (C::K - 1);
@@ -64,6 +65,19 @@ int bench(const char* name, int cin, int cout, int H) {
            n_st * a.cog_inner);
 #define RUN(ABL, label) { hipMemset(flag, 0, 64); float ms = run<C, EPI, (ABL) | 2048>(a, grid, 6); unsigned long long c[4]; hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost); \
     printf("  %-52s %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", label, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0); }
+    if (g_lat) {
+        // short list: what the DMA costs, split into issue and waiting for arrival
+        if (C::WAVES == 8 && C::MT >= 96) a.issuer_half = 1;           // as the library launches it
+        RUN(0, "baseline");
+        RUN(0, "baseline (again)");
+        RUN(0, "baseline (third)");
+        RUN(16384, "DMA issued, its arrival never waited for");
+        RUN(16384 | 4, "DMA never waited for, no barrier");
+        RUN(2, "no per-step DMA issue");
+        RUN(16, "no MFMA (everything else)");
+        RUN(16 | 16384, "no MFMA, DMA never waited for");
+        return 0;
+    }
     RUN(0, "baseline");
     RUN(0, "baseline (again)");
     { SplitArgs a0 = a; a.issuer_half = 1; RUN(0, "upper half of the waves issues all DMA"); RUN(0, "upper half issues all DMA (again)"); a = a0; }
@@ -77,6 +91,8 @@ int bench(const char* name, int cin, int cout, int H) {
     RUN(4096, "input DMA from contiguous addresses, no offset table");
     RUN(8192, "input DMA from an L2-resident 2 MB window");
     RUN(8192 | 4096, "input DMA contiguous + L2-resident");
+    RUN(16384, "DMA issued, its arrival never waited for");
+    RUN(16384 | 4, "DMA never waited for, no barrier");
     RUN(4, "no per-step barrier");
     RUN(8, "A fragments read once per step");
     RUN(1 | 2, "no epilogue, no DMA");
@@ -140,6 +156,20 @@ int main(int argc, char** argv) {
         // 1x1 projection 64 -> 128 at 4136^2 (ResidA.proj): tile shapes, same process
         quick<SplitCfg<1, 1, 128, 16, 16, 4, 8, 1, 1>, EPI_PLAIN>("K1 MT128 8w 16x16 CC4 (current)", 64, 128, 4136);
         quick<SplitCfg<1, 1, 128, 8, 16, 4, 4, 1, 1>, EPI_PLAIN>("K1 MT128 4w 8x16 CC4", 64, 128, 4136);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "lat") {
+        // is the per-step DMA cost its ISSUE or waiting for its ARRIVAL?  (round 2: the issue -- never waiting for the
+        // data changes nothing; a dedicated producer wave issuing all of it was 7 - 30 % SLOWER: one wave sustains about
+        // one 1-KiB piece per 150 cycles, the pieces have to be spread over many waves)
+        g_lat = true;
+        bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
+        bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
+        bench<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);
+        bench<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w S=2 (ResNet8 conv0)", 64, 64, 2048);
+        bench<SplitCfg<3, 4, 128, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT128 8w S=2 RES cin=64", 64, 128, 2048);
+        bench<SplitCfg<3, 8, 128, 16, 32, 2, 8, 3, 1>, EPI_RES>("K3 D8 MT128 8w RES", 128, 128, 2048);
+        bench<SplitCfg<5, 4, 128, 16, 32, 2, 8, 5, 1>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "unet") {

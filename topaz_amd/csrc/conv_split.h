@@ -183,6 +183,7 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 //   8 fragment reads only for m = 0 (operands reused)   16 no MFMAs   32 no residual loads   64 no stores
 //   128 no per-step weight DMA   256 no per-step input DMA
 //   4096 input DMA without the offset table (contiguous dummy source)   8192 input DMA from a 2 MB window (always L2 hits)
+//   16384 DMA issued but never waited for inside the K loop (what the latency of a stage's own prefetch costs)
 //   2048 clock probe: every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
 //        to the two 64-bit counters behind a.flag -> effective clock of the variant (DVFS: the chip runs at its power limit)
 template <class C, int EPI, int ABL = 0>
@@ -483,7 +484,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (C::SPS == 1 || stage_end) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this stage has landed
+                        if constexpr (!(ABL & 16384))
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this stage has landed
                         if constexpr (!(ABL & 4)) __syncthreads();
                     }
                     __builtin_amdgcn_sched_barrier(0);

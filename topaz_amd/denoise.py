@@ -277,8 +277,11 @@ def denoise_tomogram_stream(volumes: List[str], model: Denoise3D, output_path: s
     launch; the next volume is read while this one is denoised"""
     from . import parallel
     if gaus is not None and gaus > 0:
-        raise NotImplementedError('3-D Gaussian post-filter: the reference applies it to the input and discards it '
-                                  '(denoise.py:509); not implemented')
+        # upstream builds a TWO-dimensional GaussianDenoise here (denoise.py:546, dims defaults to 2) and applies it to
+        # the input volume before anything is written (:509): Conv2d rejects the 5-D tensor, so `--gaussian` > 0 has
+        # only ever raised.  Same outcome, said plainly.  (denoise_tomogram(gaus=GaussianDenoise(s, dims=3)) works.)
+        raise RuntimeError('denoise3d --gaussian: the 2-D Gaussian module cannot filter a volume (upstream fails in '
+                           'Conv2d at this point); use 0')
     rank, _, world = parallel.init_from_env()
     if output_path:
         os.makedirs(output_path, exist_ok=True)

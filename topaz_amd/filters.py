@@ -40,9 +40,12 @@ class _Filter2d:
     def apply(self, x):
         """numpy [H,W] -> numpy [H,W] (GaussianDenoise.apply, filters.py:71-80)"""
         if self.weight.ndim != 2:
-            raise NotImplementedError('3-D Gaussian post-filter is not on the hot path')
+            return self._apply_volume(x)
         y = self.forward(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))
         return y.cpu().numpy()
+
+    def _apply_volume(self, x):
+        raise NotImplementedError('only the (separable) Gaussian has a 3-D form')
 
 
 class AffineFilter(_Filter2d):
@@ -55,6 +58,25 @@ class GaussianDenoise(_Filter2d):
         f = gaussian_filter(sigma, s=width, dims=dims)
         f /= f.sum()
         super().__init__(f, use_cuda)
+        g = gaussian_filter(sigma, s=width, dims=2)[width // 2]        # the 1-D factor: exp(-r^2 / 2 sigma^2)
+        self._line = (g / g.sum()).astype(np.float64)
+
+    def _apply_volume(self, x):
+        """numpy [D,H,W] -> numpy [D,H,W]: the Conv3d(1, 1, width, padding=width//2) of filters.py:63-64.  The normalised
+        3-D Gaussian is the outer product of three normalised 1-D Gaussians, so the volume takes three zero-padded line
+        passes on the device -- along x on [D*H, W], along y on [H, D*W], along z on [D, H*W] -- each one a
+        tpz_filter_2d call whose square kernel has a single non-zero row or column."""
+        ctx = rt.get_context()
+        v = rt.as_device_f32(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), ctx)
+        D, H, W = v.shape
+        k = self._line.shape[0]
+        row = np.zeros((k, k), np.float32)
+        row[k // 2, :] = self._line
+        col = np.ascontiguousarray(row.T)
+        v = rt.filter_2d(v.reshape(D * H, W), row, 0.0, ctx).reshape(D, H, W)
+        v = rt.filter_2d(v.permute(1, 0, 2).contiguous().reshape(H, D * W), col, 0.0, ctx).reshape(H, D, W).permute(1, 0, 2)
+        v = rt.filter_2d(v.contiguous().reshape(D, H * W), col, 0.0, ctx).reshape(D, H, W)
+        return v.cpu().numpy()
 
 
 class InvGaussianFilter(_Filter2d):

@@ -28,8 +28,9 @@ class Features:
 
 
 class LinearClassifier:
-    def __init__(self, arch: str, state_dict, dims: Optional[int] = None, pooling: bool = False):
+    def __init__(self, arch: str, state_dict, dims: Optional[int] = None, pooling: bool = False, dropout: bool = False):
         self.arch = arch
+        self.dropout = bool(dropout)                 # trained with --dropout > 0 (matters to BasicConv.fill only, see pack.py)
         self.pooling = bool(pooling) or arch == 'resnet6'       # MaxPool(3, stride 2) layers (resnet.py:10-47)
         self.state_dict_np = OrderedDict((k, (v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)))
                                          for k, v in state_dict.items())
@@ -47,7 +48,7 @@ class LinearClassifier:
             units = self.state_dict_np['features.features.0.conv.weight'].shape[0]
             bn = any(k.endswith('running_mean') for k in self.state_dict_np)
         elif arch in pack.BASIC_SIZES:
-            self._program, width = pack.pack_basicconv(pack.BASIC_SIZES[arch], self.state_dict_np)
+            self._program, width = pack.pack_basicconv(pack.BASIC_SIZES[arch], self.state_dict_np, self.dropout)
             units = self.state_dict_np['features.features.0.weight'].shape[0]
             bn = any(k.endswith('running_mean') for k in self.state_dict_np)
         else:

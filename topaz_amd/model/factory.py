@@ -41,5 +41,5 @@ def load_model(path):
         arch, name = _PRETRAINED[path]
         return LinearClassifier(arch, load_state_dict_from_pkg(name))
     # user model: torch.save(model) of LinearClassifier(ResNet*/BasicConv) (factory.py:54-56, training.py:601)
-    arch, state_dict, pooling = load_module_pickle(path, with_pooling=True)
-    return LinearClassifier(arch, state_dict, pooling=pooling)
+    arch, state_dict, traits = load_module_pickle(path, with_traits=True)
+    return LinearClassifier(arch, state_dict, pooling=traits['pooling'], dropout=traits['dropout'])

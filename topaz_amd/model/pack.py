@@ -142,16 +142,43 @@ def basic_width(sizes: Sequence[int]) -> int:
     return out
 
 
-def pack_basicconv(sizes: Sequence[int], sd) -> Tuple[LayerProgram, int]:
-    """filled basic.BasicConv (basic.py:81-89: dilation = cumulative stride 1,2,4,..) + 1x1 head"""
+def basic_fill_dilations(n_convs: int, has_bn: bool, dropout: bool = False) -> List[int]:
+    """dilation BasicConv.fill() gives each conv (basic.py:81-89).  fill() walks the layer list zipped with `strides`,
+    and the constructor appends no `strides` entry for its nn.Dropout layers (basic.py:57-58,69-70): without dropout the
+    result is the cumulative stride 1, 2, 4, ...; a model trained with --dropout has the pairs slip by one per Dropout
+    (conv31: 1, 4, 4) and that is what upstream's `extract` then scores with -- reproduced here, not corrected."""
+    kinds, strides = [], []
+    for i in range(n_convs):
+        last = i == n_convs - 1
+        kinds.append('conv')
+        strides.append(1 if last else 2)
+        if has_bn:
+            kinds.append('bn')
+            strides.append(1)
+        kinds.append('act')
+        strides.append(1)
+        if dropout:
+            kinds.append('drop')
+    dils, stride = [], 1
+    for kind, st in zip(kinds, strides):
+        if kind == 'conv':
+            dils.append(stride)
+        stride *= st
+    return dils + [1] * (n_convs - len(dils))        # convs past the end of the zip keep dilation 1 (and their stride 1)
+
+
+def pack_basicconv(sizes: Sequence[int], sd, dropout: bool = False) -> Tuple[LayerProgram, int]:
+    """filled basic.BasicConv (basic.py:81-89: dilation = cumulative stride 1,2,4,..) + 1x1 head.  `sd` is numbered
+    without Dropout modules (unpickle.py renumbers); `dropout` only selects upstream's fill pattern for such models."""
     sd = _np(sd)
     has_bn = any(k.endswith('running_mean') for k in sd)
     width = basic_width(sizes)
+    dils = basic_fill_dilations(len(sizes), has_bn, dropout)
     P = LayerProgram(2)
     pre = 'features.features.'
     head_w = sd['classifier.weight'].reshape(-1)
     head_b = float(sd['classifier.bias'].reshape(-1)[0])
-    cur, idx, dil = 0, 0, 1
+    cur, idx = 0, 0
     for li, k in enumerate(sizes):
         w, b = sd[f'{pre}{idx}.weight'], sd.get(f'{pre}{idx}.bias')
         idx += 1
@@ -162,8 +189,7 @@ def pack_basicconv(sizes: Sequence[int], sd) -> Tuple[LayerProgram, int]:
         idx += 1
         last = li == len(sizes) - 1
         kw = dict(head_w=head_w, head_b=head_b) if last else {}
-        cur = P.conv(cur, w, b, dil=dil, pad=width // 2 if li == 0 else 0, slope=slope, **kw)
-        dil *= 2 if not last else 1
+        cur = P.conv(cur, w, b, dil=dils[li], pad=width // 2 if li == 0 else 0, slope=slope, **kw)
     return P, width
 
 

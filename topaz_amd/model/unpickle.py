@@ -105,9 +105,28 @@ def _walk(mod, prefix, out):
             _walk(m, prefix + k + '.', out)
 
 
-def load_module_pickle(path, with_pooling: bool = False):
-    """(arch, state_dict) of a pickled LinearClassifier; with_pooling=True adds whether the feature stack holds MaxPool
-    layers (`topaz train --pooling max`, ResNet6)."""
+def _without_dropout(sd, kinds):
+    """state_dict renumbered as if the nn.Dropout entries of features.features were not there (identity at inference;
+    they only shift the index of every later module: resnet.py:296-303, basic.py:57-70)"""
+    new_index, n = {}, 0
+    for i, kind in enumerate(kinds):
+        if kind != 'Dropout':
+            new_index[str(i)] = str(n)
+            n += 1
+    out = OrderedDict()
+    pre = 'features.features.'
+    for k, v in sd.items():
+        if k.startswith(pre):
+            idx, _, rest = k[len(pre):].partition('.')
+            k = f'{pre}{new_index[idx]}.{rest}'
+        out[k] = v
+    return out
+
+
+def load_module_pickle(path, with_traits: bool = False):
+    """(arch, state_dict) of a pickled LinearClassifier; with_traits=True adds {'pooling': the feature stack holds MaxPool
+    layers (`topaz train --pooling max`, ResNet6), 'dropout': it was trained with --dropout > 0}.  The state_dict is
+    numbered without the Dropout modules."""
     obj = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_PickleModule)
     if isinstance(obj, (dict, OrderedDict)) and all(torch.is_tensor(v) for v in obj.values()):
         raise ValueError(f'{path} holds a bare state_dict; the architecture cannot be inferred. '
@@ -120,22 +139,24 @@ def load_module_pickle(path, with_pooling: bool = False):
     fname = fq.rsplit('.', 1)[-1]
     sd = OrderedDict()
     _walk(obj, '', sd)
-    pooling = False
+    mods = feats.__dict__['_modules']['features'].__dict__['_modules']
+    kinds = [type(m).__name__ for m in mods.values()]
+    pooling = 'MaxPool' in kinds
+    dropout = 'Dropout' in kinds
     if fname in ('ResNet6', 'ResNet8', 'ResNet16'):
         arch = fname.lower()
-        mods = feats.__dict__['_modules']['features'].__dict__['_modules']
-        kinds = [type(m).__name__ for m in mods.values()]
-        pooling = 'MaxPool' in kinds
         if any(k not in ('BasicConv', 'ResidA', 'MaxPool', 'Dropout') for k in kinds):
             raise NotImplementedError(f'{path}: {arch} with layers {sorted(set(kinds))} is not supported on the MI355X path')
-        if 'Dropout' in kinds:
-            # nn.Dropout modules shift the indices of features.features; inference ignores them
-            raise NotImplementedError(f'{path}: models trained with --dropout > 0 are not supported yet')
     elif fname in ('BasicConv', 'Conv127', 'Conv63', 'Conv31'):
-        n_convs = sum(1 for k, v in sd.items() if k.startswith('features.features.') and v.dim() == 4)
+        if any(not (k.startswith(('Conv', 'BatchNorm')) or k in ('PReLU', 'Dropout')) for k in kinds):
+            raise NotImplementedError(f'{path}: BasicConv with layers {sorted(set(kinds))} is not supported on the MI355X '
+                                      f'path (strided PReLU stacks only: no pooling, no other activation)')
+        n_convs = sum(1 for k in kinds if k.startswith('Conv'))
         arch = {5: 'conv127', 4: 'conv63', 3: 'conv31'}.get(n_convs)
         if arch is None:
             raise ValueError(f'{path}: BasicConv with {n_convs} convolutions is not a conv127/63/31 stack')
     else:
         raise NotImplementedError(f'{path}: feature extractor {fname} is not supported on the MI355X path')
-    return (arch, sd, pooling) if with_pooling else (arch, sd)
+    if dropout:
+        sd = _without_dropout(sd, kinds)
+    return (arch, sd, {'pooling': pooling, 'dropout': dropout}) if with_traits else (arch, sd)
