@@ -549,10 +549,14 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const int l15 = tid_e & 15, l4 = (tid_e >> 4) & 3;
         const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
         const int fz = oz * a.os + ooz;                      // output plane in the full tensor (0 in 2-D)
-        const size_t plane_out = (size_t)a.cells_out * a.Dfull * a.Hfull * a.Wfull;
-        const size_t plane_res = (size_t)a.cells_out * a.Dres * a.Hres * a.Wres;
+        const size_t cplane_out = (size_t)a.Dfull * a.Hfull * a.Wfull, cplane_res = (size_t)a.Dres * a.Hres * a.Wres;   // one cell plane
+        const size_t plane_out = (size_t)a.cells_out * cplane_out;
+        const size_t plane_res = (size_t)a.cells_out * cplane_res;
+        const size_t zoff_out = (size_t)fz * a.Hfull * a.Wfull, zoff_res = (size_t)fz * a.Hres * a.Wres;
         const bool has_bias = a.bias != nullptr;
-        int fyv[NW], fxv[NW];
+        // Addresses: pixel part (per n, 32-bit cell index inside one cell plane) + cell part (per m, 64-bit) -- one 64-bit
+        // add per access.  Invalid pixels and cells are CLAMPED (loads stay in range) and carry a predicate on the store.
+        unsigned opix[NW], rpix[NW];
         bool okv[NW];
         if constexpr (EPI != EPI_HEAD) {       // (the fused head stores nothing here: every pixel just accumulates)
 #pragma unroll
@@ -560,12 +564,20 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int oy = y0 + (wave * C::RPW + n / NFC) * D;
                 const int ox = x0 + (n % NFC) * 16 + l15;
                 okv[n] = oy < a.Hout && ox < a.Wout;
-                if constexpr ((ABL & 1) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
-                const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;   // clamped: loads stay in range
-                fyv[n] = cy * a.os + ooy;
-                fxv[n] = cx * a.os + oox;
+                if constexpr ((ABL & 1) != 0 || (ABL & 64) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
+                const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;
+                const int fy = cy * a.os + ooy, fx = cx * a.os + oox;
+                if constexpr (EPI == EPI_POOL) opix[n] = (unsigned)((cy >> 1) * a.Wfull + (cx >> 1));
+                else opix[n] = (unsigned)(fy * a.Wfull + fx);
+                rpix[n] = (unsigned)((fy + a.res_crop) * a.Wres + fx + a.res_crop);
+                if constexpr (EPI == EPI_POOL) {
+                    // the even row / even column of each 2x2 window stores its maximum (floor: a window must be whole)
+                    okv[n] = (l15 & 1) == 0 && oy + 1 < a.Hout && ox + 1 < a.Wout;
+                }
             }
         }
+        const float slope = a.slope;
+        u16x2 bigacc = {0, 0};                 // running maximum of |hi| bit patterns: >= 0x7c00 <=> an inf / NaN half
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // 4 consecutive (virtual) channels: half a cell
@@ -577,32 +589,38 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 if (par > 3) co0 = a.Cout;                         // padding fragments of the last co-group
             }
             const int cell = co0 >> 3, half = (co0 >> 2) & 1;
-            const int cellc = cell < a.cells_out ? cell : a.cells_out - 1;
-            // per-channel constants: one float4 each (arrays zero-padded to whole tiles: no clamps, padded channels -> 0)
-            float sc[4], bi[4], psc[4], psh[4], hw[4];
+            const bool cell_ok = cell < a.cells_out;
+            const int cellc = cell_ok ? cell : a.cells_out - 1;
+            // per-channel constants: one float4 each.  Every array is zero-padded to whole tiles, so the channels that pad
+            // the last cell come out as 0 * acc + 0 = 0 without a mask (their residual cells hold zeros as well)
+            // (kept as channel PAIRS: the arithmetic below is written on two-wide vectors -> v_pk_fma / v_pk_mul / v_pk_add)
+            f32x2 sc[2], bi[2], psc[2], psh[2], hw[2];
             {
                 const float4 s4 = *reinterpret_cast<const float4*>(wscale + cov0);
-                sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
+                sc[0] = (f32x2){s4.x, s4.y}; sc[1] = (f32x2){s4.z, s4.w};
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (has_bias) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
-                bi[0] = b4.x; bi[1] = b4.y; bi[2] = b4.z; bi[3] = b4.w;
+                bi[0] = (f32x2){b4.x, b4.y}; bi[1] = (f32x2){b4.z, b4.w};
                 if constexpr (EPI == EPI_RES_POST) {
                     const float4 p4 = *reinterpret_cast<const float4*>(a.post_scale + co0);
                     const float4 q4 = *reinterpret_cast<const float4*>(a.post_shift + co0);
-                    psc[0] = p4.x; psc[1] = p4.y; psc[2] = p4.z; psc[3] = p4.w;
-                    psh[0] = q4.x; psh[1] = q4.y; psh[2] = q4.z; psh[3] = q4.w;
+                    psc[0] = (f32x2){p4.x, p4.y}; psc[1] = (f32x2){p4.z, p4.w};
+                    psh[0] = (f32x2){q4.x, q4.y}; psh[1] = (f32x2){q4.z, q4.w};
                 }
                 if constexpr (EPI == EPI_HEAD) {
                     const float4 h4 = *reinterpret_cast<const float4*>(a.head_w + co0);
-                    hw[0] = h4.x; hw[1] = h4.y; hw[2] = h4.z; hw[3] = h4.w;
+                    hw[0] = (f32x2){h4.x, h4.y}; hw[1] = (f32x2){h4.z, h4.w};
                 }
             }
+            const f32x2 slope2 = {slope, slope};
+            // this lane's half cell of plane `cell` at pixel 0 (+ the sub-pixel parity shift): hi plane; lo = + plane_out
+            uint2* const ob = reinterpret_cast<uint2*>(a.out + ((size_t)cellc * cplane_out + zoff_out + (unsigned)(sy * a.Wfull + sx))) + half;
             uint2 rh[NW], rl[NW];
             if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) {
+                const uint2* const rb = reinterpret_cast<const uint2*>(a.res + ((size_t)cellc * cplane_res + zoff_res + (unsigned)(sy * a.Wres + sx))) + half;
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
-                    const size_t rc = (((size_t)cellc * a.Dres + fz) * a.Hres + (fyv[n] + sy + a.res_crop)) * a.Wres + (fxv[n] + sx + a.res_crop);
-                    const uint2* rp = reinterpret_cast<const uint2*>(a.res + rc) + half;
+                    const uint2* rp = rb + 2 * (size_t)rpix[n];
                     rh[n] = rp[0];
                     rl[n] = rp[plane_res * 2];
                 }
@@ -612,67 +630,70 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
                     if ((n / NFC) % 2 != 0) continue;                 // the even row of each pair handles the pair
-                    float v[4];
+                    f32x2 v[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t0 = acc[m][n][r] * sc[r] + bi[r], t1 = acc[m][n + NFC][r] * sc[r] + bi[r];
-                        t0 = t0 > 0.f ? t0 : t0 * a.slope;
-                        t1 = t1 > 0.f ? t1 : t1 * a.slope;
-                        float t = fmaxf(t0, t1);                       // rows y, y + 1
-                        t = fmaxf(t, __shfl_xor(t, 1, 64));            // columns x, x + 1 (neighbouring lanes)
-                        v[r] = co0 + r < a.Cout ? t : 0.f;
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 t0 = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + bi[h];
+                        f32x2 t1 = (f32x2){acc[m][n + NFC][2 * h], acc[m][n + NFC][2 * h + 1]} * sc[h] + bi[h];
+                        t0 = __builtin_elementwise_max(t0, t0 * slope2);
+                        t1 = __builtin_elementwise_max(t1, t1 * slope2);
+                        const f32x2 t = __builtin_elementwise_max(t0, t1);                       // rows y, y + 1
+                        v[h] = __builtin_elementwise_max(t, (f32x2){__shfl_xor(t[0], 1, 64), __shfl_xor(t[1], 1, 64)});   // columns x, x + 1
                     }
-                    const int oy = y0 + wave * C::RPW + n / NFC, ox = x0 + (n % NFC) * 16 + l15;
-                    if ((l15 & 1) == 0 && oy + 1 < a.Hout && ox + 1 < a.Wout) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);
-                        if (cell < a.cells_out) {
-                            uint2 hi, lo;
-                            split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + ((size_t)cell * a.Hfull + (oy >> 1)) * a.Wfull + (ox >> 1)) + half;
-                            op[0] = hi;
-                            op[plane_out * 2] = lo;
-                        }
+                    if (okv[n] && cell_ok) {
+                        uint2 hi, lo;
+                        split2(v[0], hi.x, lo.x);
+                        split2(v[1], hi.y, lo.y);
+                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & 0x7fff7fffu));
+                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & 0x7fff7fffu));
+                        uint2* op = ob + 2 * (size_t)opix[n];
+                        op[0] = hi;
+                        op[plane_out * 2] = lo;
                     }
                 }
                 continue;
             }
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
-                float v[4];
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) join4(rh[n], rl[n], rv);
+                f32x2 v[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[m][n][r] * sc[r] + bi[r];
-                    if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) v[r] += rv[r];
-                    if constexpr (EPI == EPI_RES_POST) v[r] = v[r] * psc[r] + psh[r];
-                    v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
-                    if (co0 + r >= a.Cout) v[r] = 0.f;
-                    if constexpr (EPI == EPI_HEAD) v[r] *= hw[r];
+                for (int h = 0; h < 2; ++h) {
+                    v[h] = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + bi[h];
+                    if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32))
+                        v[h] += h ? join2(rh[n].y, rl[n].y) : join2(rh[n].x, rl[n].x);
+                    if constexpr (EPI == EPI_RES_POST) v[h] = v[h] * psc[h] + psh[h];
+                    v[h] = __builtin_elementwise_max(v[h], v[h] * slope2);   // v > 0 ? v : v * slope for every slope <= 1 (host: no others here)
+                    if constexpr (EPI == EPI_HEAD) v[h] *= hw[h];
                 }
                 if constexpr (EPI == EPI_HEAD) {
-                    hsum[n] += (v[0] + v[1]) + (v[2] + v[3]);
+                    const f32x2 t = v[0] + v[1];
+                    hsum[n] += t[0] + t[1];
                 } else if constexpr (EPI == EPI_PLAIN_F32) {
+                    // fp32 planes [Cout][D][H][W]: four channel planes per lane
+                    const size_t cs = cplane_out;
+                    float* const fb = a.out_f32 + ((size_t)co0 * cplane_out + zoff_out + (unsigned)(sy * a.Wfull + sx)) + opix[n];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (okv[n] && co0 + r < a.Cout)
-                            a.out_f32[(((size_t)(co0 + r) * a.Dfull + fz) * a.Hfull + fyv[n] + sy) * a.Wfull + fxv[n] + sx] = v[r];
+                        if (okv[n] && co0 + r < a.Cout) fb[r * cs] = v[r >> 1][r & 1];
                 } else {
-                    if (okv[n] && (!(ABL & 64) || a.slope == 12345.f)) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) big |= !(fabsf(v[r]) <= SPLIT_MAX);      // also true for NaN
-                        if (cell < a.cells_out) {
-                            uint2 hi, lo;
-                            split4(v, hi, lo);
-                            uint2* op = reinterpret_cast<uint2*>(a.out + (((size_t)cell * a.Dfull + fz) * a.Hfull + fyv[n] + sy) * a.Wfull + fxv[n] + sx) + half;
-                            op[0] = hi;
-                            op[plane_out * 2] = lo;
-                        }
+                    // (everything but the two stores outside the predicate: a long predicated block gets a skip branch, and
+                    // at every branch target the compiler waits for ALL outstanding memory operations -- the previous
+                    // fragment's stores included.  Pixels past the edge compute on zero-filled input: finite values.)
+                    uint2 hi, lo;
+                    split2(v[0], hi.x, lo.x);
+                    split2(v[1], hi.y, lo.y);
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & 0x7fff7fffu));
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & 0x7fff7fffu));
+                    uint2* op = ob + 2 * (size_t)opix[n];
+                    asm volatile("" : "+v"(lo.x), "+v"(lo.y));     // (keeps the lo arithmetic from being sunk into the predicated block)
+                    if (okv[n] && cell_ok) {
+                        op[0] = hi;
+                        op[plane_out * 2] = lo;
                     }
                 }
             }
         }
+        big = big || bigacc[0] >= 0x7c00 || bigacc[1] >= 0x7c00;
     }  // co-group loop
 
     if constexpr ((ABL & 2048) != 0) {

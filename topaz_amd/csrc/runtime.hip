@@ -809,6 +809,9 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
     for (int i = 0; i < nl; ++i) {
         LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
+        // the split epilogue applies the activation as max(v, slope * v): right for every slope <= 1 (ReLU, LeakyReLU,
+        // identity, PReLU as trained); a layer with a larger slope stays on its fp32 kernel
+        if (L.op == TPZ_OP_CONV && L.slope > 1.f) continue;
         if (L.op == TPZ_OP_CONV && !rt.ki && L.cout == 1 && L.cin % 8 == 0 && L.src2 < 0 && L.res < 0 && !L.head &&
             L.post_scale_off < 0 && L.dil == 1 && L.pad == L.k / 2 && L.slope == 1.f && i == nl - 1) {
             // 1-output-channel last conv: its kx taps as k virtual output channels of a k x 1 column kernel
@@ -853,7 +856,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         if (rt.ki && rt.ki->cin1 && L.src2 < 0) {
             if (!(wanted && L.res < 0 && !L.head && L.post_scale_off < 0)) continue;
             // stem: a k x 1 column kernel over an x-shifted copy of the image (kx taps as 8*ncell input channels) ...
-            if (L.dil == 1) rt.ks_stem = pick_split(L.k, 1, L.cout, EPI_PLAIN, 1);
+            if (L.dil == 1 && !(L.slope > 1.f)) rt.ks_stem = pick_split(L.k, 1, L.cout, EPI_PLAIN, 1);
             if (rt.ks_stem) {
                 const int k = L.k, kz_n = L.dims == 3 ? k : 1, c8 = (k + 7) / 8 * 8;
                 std::vector<float> w2((size_t)L.cout * c8 * kz_n * k, 0.f);
