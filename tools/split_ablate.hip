@@ -76,6 +76,12 @@ int bench(const char* name, int cin, int cout, int H) {
         RUN(2, "no per-step DMA issue");
         RUN(16, "no MFMA (everything else)");
         RUN(16 | 16384, "no MFMA, DMA never waited for");
+        RUN(16 | 2, "no MFMA, no DMA issue");
+        RUN(16 | 8, "no MFMA, fragment reads for m = 0 only");
+        RUN(16 | 4, "no MFMA, no barrier");
+        RUN(16 | 2 | 4, "no MFMA, no DMA, no barrier");
+        RUN(16 | 2 | 4 | 8, "no MFMA, no DMA, no barrier, few LDS reads");
+        RUN(16 | 2 | 4 | 8 | 1, "  ... and no epilogue loads/stores (loop skeleton + prologue)");
         return 0;
     }
     RUN(0, "baseline");
@@ -163,6 +169,12 @@ int main(int argc, char** argv) {
         // data changes nothing; a dedicated producer wave issuing all of it was 7 - 30 % SLOWER: one wave sustains about
         // one 1-KiB piece per 150 cycles, the pieces have to be spread over many waves)
         g_lat = true;
+        if (argc > 2) {        // the narrow tiles only
+            bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
+            bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
+            bench<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w S=2 (ResNet8 conv0)", 64, 64, 2048);
+            return 0;
+        }
         bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
         bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
         bench<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);

@@ -270,6 +270,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
 
+    // One LDS-DMA instruction (16 bytes per lane, 1 KiB per wave) from a PER-LANE source address: lanes whose cell lies
+    // outside the image (or past the last channel) read the zero block instead, a lane of the plane-stacked 3-D mode picks
+    // its own source tensor -- no divergent paths around the instruction, and M0 is the compiler's to set.
+    auto glds16 = [&](const void* src, unsigned lds_addr) {
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                         (__attribute__((address_space(3))) void*)(size_t)lds_addr, 16, 0, 0);
+    };
     // round r of the input tile of chunk ch -> input buffer buf (both planes)
     auto issue_input = [&](int ch, int buf, int r, int tid, int wave) {
         const int g = r * C::THREADS + tid;
@@ -278,11 +285,11 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * a.Hin * a.Win
                                         : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
             if constexpr ((ABL & 8192) != 0) chunk = a.in;            // (ABL 8192: every tile reads one L2-resident window)
-            const void* bhi = uniform_ptr(vol ? a.in : chunk);
-            const void* blo = uniform_ptr((vol ? a.in : chunk) + ((ABL & 8192) ? (size_t)0x20000 : second ? plane2 : plane1));
+            const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
+            size_t lo_delta = ((ABL & 8192) ? (size_t)0x20000 : second ? plane2 : plane1) * 16;      // bytes from a hi cell to its lo cell
             unsigned off = (ABL & 4096) ? (unsigned)g * 16u : lds_tab[g];      // (ABL 4096: no table, contiguous source)
             if constexpr ((ABL & 8192) != 0) off = off == OOB ? off : (off & 0x1ffff0u);
-            bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
+            const unsigned char* src = bhi;
             if (!vol) {
                 if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
             } else {
@@ -293,38 +300,27 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int iz = oz + kz - pad_z;
                 if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
                 else if (off != OOB) {
-                    lane2 = c >= a.cells_in1;
+                    const bool lane2 = c >= a.cells_in1;             // this lane's cell comes from `in2`
                     off += (unsigned)((((size_t)(lane2 ? c - a.cells_in1 : c) * a.Din + iz) * a.Hin) * a.Win * 16);
+                    if (lane2) { src = reinterpret_cast<const unsigned char*>(a.in2); lo_delta = plane2 * 16; }
                 }
             }
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
-            if (!__any(off == OOB || lane2)) {
-                glds_b128(off, bhi, dst);
-                glds_b128(off, blo, dst + C::PLANE_BYTES);
-            } else {
-                if (off == OOB) {
-                    glds_b128(0u, zsrc, dst);
-                    glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
-                } else if (lane2) {
-                    const void* b2 = uniform_ptr(a.in2);
-                    const void* b2lo = uniform_ptr(a.in2 + plane2);
-                    glds_b128(off, b2, dst);
-                    glds_b128(off, b2lo, dst + C::PLANE_BYTES);
-                } else {
-                    glds_b128(off, bhi, dst);
-                    glds_b128(off, blo, dst + C::PLANE_BYTES);
-                }
-            }
+            const bool oob = off == OOB;
+            const unsigned char* shi = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off;
+            const unsigned char* slo = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off + lo_delta;
+            glds16(shi, dst);
+            glds16(slo, dst + C::PLANE_BYTES);
         }
     };
     // weights of stage `stg` (its steps that exist: `bytes` = min(SPS, steps left) * W_STEP_BYTES) -> weight buffer `buf`
     auto issue_weights = [&](const unsigned char* wcog, int stg, int bytes, int buf, int tid, int wave) {
-        const void* base = uniform_ptr(wcog + (size_t)stg * C::W_STAGE_BYTES);
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(uniform_ptr(wcog + (size_t)stg * C::W_STAGE_BYTES));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STAGE_BYTES + wave * 1024));
 #pragma unroll
         for (int i = 0; i < C::WR; ++i)
             if ((i * C::WAVES + wave) * 1024 < bytes)                  // whole waves (1 KiB each)
-                glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
+                glds16(base + (unsigned)(i * C::THREADS + tid) * 16u, dst + i * C::THREADS * 16);
     };
 
     // per-lane LDS read bases (bytes)
