@@ -24,6 +24,8 @@ Prints ONE JSON line (see the driver contract) including
   exact_fp32   -- the same step with every convolution pinned to the fp32-MFMA kernels (tpz_ctx_set_exact)
   pcie_inclusive -- the same step fed from pinned host memory through the host-pointer entry points (H2D of the
                   micrograph, D2H of the pick table, double-buffered), N=1 only.
+  full_patch_tensors -- the same step with the patch windows off (tpz_ctx_set_roi(0)): every layer of every denoise patch
+                  computes its whole tensor although only the patch centre is kept.  Same output, bit for bit.
 `--dry-run` (CPU box, no GPU): skips the hot path and fabricates pick tables so that the launcher, the barriers and the
 gather can be exercised over gloo; its line carries "dry_run": true and is not a measurement.
 """
@@ -356,6 +358,20 @@ def main():
                                 'note': 'every convolution on the fp32-MFMA kernels (tpz_ctx_set_exact): exact fp32 '
                                         'multiplies, peak 157.3 TFLOP/s'}
         extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
+        if args.workload != 'extract':
+            # A/B of the patch windows: the same step with every tensor of every denoise patch computed in full
+            ctx.set_roi(False)
+            try:
+                run_step(models, imgs[0], args)
+                t, _ = timed_steps(models, imgs, args, dev, 2)
+            finally:
+                ctx.set_roi(True)
+            extras['full_patch_tensors'] = {
+                'value': 2 / t, 'ms_per_step': 1e3 * t / 2, 'steps': 2, 'unit': 'micrographs/s',
+                'note': 'tpz_ctx_set_roi(0): every layer of a denoise patch computes its whole 2024^2 tensor, as the '
+                        'reference does, although only the 1024^2 centre of a patch is kept; `value` above computes, per '
+                        'layer, only the rectangle those kept pixels depend on -- bit-identical output '
+                        '(tests/test_gpu_denoise.py::test_patch_windows_are_bit_identical)'}
 
     if rank == 0:
         out = {
@@ -381,6 +397,8 @@ def main():
                 'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps,
                 'parallelism': f'one micrograph per rank x{world}; RCCL gather of pick tables',
                 'picks_per_image': n_picks / max(1, len(scs)) if have_picks else None,
+                'patch_windows': 'on: a denoise patch computes, layer by layer, only what its kept 1024^2 centre depends on '
+                                 '(bit-identical to computing the 2024^2 tensors in full; full_patch_tensors = the A/B leg)',
             },
             'gather_ms': 1e3 * t_gather,
             # the dominant kernel = the conv instantiation with the most time in a step (live HIP-event timing of the

@@ -208,6 +208,12 @@ int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
  * On by default (TPZ_NO_LANES=1 in the environment or on = 0 here: everything on the ctx stream, e.g. to time kernels in
  * isolation).  Results are bit-identical either way. */
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
+/* Patch windows: a patch of tpz_denoise_2d keeps only its centre (topaz/denoise.py:299-323: patch_size pixels of a
+ * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the
+ * U-Net's receptive field is ~230 pixels, the CLI's default padding 500).  The statistics of the normalisation are still the
+ * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
+ * (TPZ_NO_ROI=1 in the environment or on = 0 here). */
+int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
 int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns);
 /* One 2-D convolution on the 2xf16 kernels with fp32 [C][H][W] tensors at the boundary (converted on the device):
  * unit-test / interop entry; arguments as tpz_conv (single source).  *overflow = 1 when a result left the f16 range. */

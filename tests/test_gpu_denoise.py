@@ -137,6 +137,45 @@ def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):
         assert _err(y[i:i + pz, j:j + py, k:k + px], ref) <= ATOL, (i, j, k)
 
 
+@pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'tight_padding'])
+def test_patch_windows_are_bit_identical(gpu_ctx, case):
+    """a patch keeps only its centre, so every layer computes only the rectangle the kept pixels depend on
+    (runtime.hip need_regions): the output must not change by one bit against computing every tensor in full --
+    corner, edge and interior patches, odd sizes (pooled sizes not divisible by two), windows clipped at the borders,
+    padding smaller than the receptive field (nothing to save: the windows must then cover everything)"""
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    if case == 'bench_net':
+        d = Denoise(DenoiseNet('unet', oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)))
+        shape, patch, pad = (1500, 1330), 400, 300
+    elif case == 'pretrained':
+        d = Denoise('unet-v0.2.1')
+        shape, patch, pad = (1111, 1201), 256, 280
+    elif case == 'small':
+        d = Denoise('unet-small')
+        shape, patch, pad = (700, 900), 200, 120
+    elif case == 'fcnn':
+        d = Denoise('fcnn')
+        shape, patch, pad = (500, 640), 128, 64
+    else:
+        d = Denoise('unet-v0.2.1')
+        shape, patch, pad = (600, 700), 192, 40
+    x = (np.random.RandomState(77).randn(*shape) * 3 + 1).astype(np.float32)
+    try:
+        gpu_ctx.set_roi(False)
+        full = d.denoise(x, patch, pad)
+        gpu_ctx.set_roi(True)
+        win = d.denoise(x, patch, pad)
+    finally:
+        gpu_ctx.set_roi(True)
+    assert np.isfinite(full).all()
+    assert np.array_equal(full, win)
+    eligible, split_runs, fp32_reruns = d.model.device_model.split_stats()
+    assert fp32_reruns == 0            # (a window never raises the overflow flag on pixels nobody computed)
+    if case != 'fcnn':
+        assert eligible and split_runs >= 2
+
+
 def test_edge_cases(gpu_ctx):
     from topaz_amd._lib import TopazHipError
     from topaz_amd.denoise import Denoise

@@ -88,6 +88,10 @@ struct SplitArgs {
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
     int xcd_swizzle;
+    // output WINDOW of the launch, in its own lattice coordinates: the tiles cover [wy0, wy1) x [wx0, wx1) only and nothing
+    // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
+    // centre, so every layer computes only the part of its tensor that the kept pixels depend on (runtime.hip, need_regions).
+    int wy0, wx0, wy1, wx1;
 };
 
 struct SplitSlot {
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         bx = (int)(wgid % gridDim.x);
         by = (int)(wgid / gridDim.x);
     }
-    const int y0 = (by / D) * (C::TH * D) + (by % D);
-    const int x0 = bx * C::TW;
+    const int y0 = a.wy0 + (by / D) * (C::TH * D) + (by % D);
+    const int x0 = a.wx0 + bx * C::TW;
     const int cogz = (int)blockIdx.z % a.ncz;
     int oz = (int)blockIdx.z / a.ncz;                        // output plane of the launch lattice (0 in 2-D)
     int pad_x = a.pad_x, pad_y = a.pad_y, pad_z = a.pad_z, oox = a.oox, ooy = a.ooy, ooz = a.ooz, phase = 0;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             for (int n = 0; n < NW; ++n) {
                 const int oy = y0 + (wave * C::RPW + n / NFC) * D;
                 const int ox = x0 + (n % NFC) * 16 + l15;
-                okv[n] = oy < a.Hout && ox < a.Wout;
+                okv[n] = oy < a.wy1 && ox < a.wx1;               // (wy1 <= Hout, wx1 <= Wout)
                 if constexpr ((ABL & 1) != 0 || (ABL & 64) != 0) okv[n] = okv[n] && (a.slope == 12345.f);
                 const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;
                 const int fy = cy * a.os + ooy, fx = cx * a.os + oox;
@@ -568,12 +572,17 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 rpix[n] = (unsigned)((fy + a.res_crop) * a.Wres + fx + a.res_crop);
                 if constexpr (EPI == EPI_POOL) {
                     // the even row / even column of each 2x2 window stores its maximum (floor: a window must be whole)
-                    okv[n] = (l15 & 1) == 0 && oy + 1 < a.Hout && ox + 1 < a.Wout;
+                    okv[n] = (l15 & 1) == 0 && oy < a.wy1 && ox < a.wx1 && oy + 1 < a.Hout && ox + 1 < a.Wout;
                 }
             }
         }
         const float slope = a.slope;
         u16x2 bigacc = {0, 0};                 // running maximum of |hi| bit patterns: >= 0x7c00 <=> an inf / NaN half
+        // ... of the pixels that are stored only: a tile may overhang the launch window, and what lies outside a producer's
+        // window was never written (any bit pattern)
+        unsigned okmask[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) okmask[n] = (EPI != EPI_HEAD && okv[n]) ? 0x7fff7fffu : 0u;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // 4 consecutive (virtual) channels: half a cell
@@ -640,8 +649,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         uint2 hi, lo;
                         split2(v[0], hi.x, lo.x);
                         split2(v[1], hi.y, lo.y);
-                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & 0x7fff7fffu));
-                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & 0x7fff7fffu));
+                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & okmask[n]));
+                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & okmask[n]));
                         uint2* op = ob + 2 * (size_t)opix[n];
                         op[0] = hi;
                         op[plane_out * 2] = lo;
@@ -674,12 +683,12 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 } else {
                     // (everything but the two stores outside the predicate: a long predicated block gets a skip branch, and
                     // at every branch target the compiler waits for ALL outstanding memory operations -- the previous
-                    // fragment's stores included.  Pixels past the edge compute on zero-filled input: finite values.)
+                    // fragment's stores included)
                     uint2 hi, lo;
                     split2(v[0], hi.x, lo.x);
                     split2(v[1], hi.y, lo.y);
-                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & 0x7fff7fffu));
-                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & 0x7fff7fffu));
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & okmask[n]));
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & okmask[n]));
                     uint2* op = ob + 2 * (size_t)opix[n];
                     asm volatile("" : "+v"(lo.x), "+v"(lo.y));     // (keeps the lo arithmetic from being sunk into the predicated block)
                     if (okv[n] && cell_ok) {
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             float h = hsum[n];
             h += __shfl_xor(h, 16, 64);
             h += __shfl_xor(h, 32, 64);
-            if (l4 == 0 && oy < a.Hout && ox < a.Wout) a.head_out[(size_t)oy * a.Wout + ox] = h + a.head_b;
+            if (l4 == 0 && oy < a.wy1 && ox < a.wx1) a.head_out[(size_t)oy * a.Wout + ox] = h + a.head_b;
         }
     } else if constexpr (EPI != EPI_PLAIN_F32) {
         if (__any(big) && lane == 0) atomicOr(a.flag, 1u);

@@ -584,18 +584,21 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
     if (big && flag) atomicOr(flag, 1u);      // pixel values beyond the f16 range: the caller re-runs in fp32
 }
 
+// (only rows [y0, y1) x columns [x0, x1) of the 2-D output are produced: the window of the layer, runtime.hip)
 __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
                                                        size_t rows, int W, int Wp, float bias,
-                                                       const float* __restrict__ nrm, int norm_out) {
-    const size_t n = rows * W;
+                                                       const float* __restrict__ nrm, int norm_out, size_t y0, size_t y1,
+                                                       int x0, int x1) {
+    const int nx = x1 - x0;
+    const size_t n = (y1 - y0) * nx;
     float sc = 1.f, sh = 0.f;
     if (nrm && norm_out) { sc = nrm[2]; sh = nrm[3]; }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W);
-        const size_t row = i / W;
+        const int x = x0 + (int)(i % nx);
+        const size_t row = y0 + i / nx;
         float acc = 0.f;
         for (int v = 0; v < K; ++v) acc += Y[((size_t)v * rows + row) * Wp + x + v];
-        out[i] = (acc + bias) * sc + sh;
+        out[row * W + x] = (acc + bias) * sc + sh;
     }
 }
 
@@ -608,10 +611,13 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
     return hipGetLastError();
 }
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
-                           int norm_out, hipStream_t s) {
-    const size_t n = rows * W;
+                           int norm_out, hipStream_t s, size_t y0, size_t y1, int x0, int x1) {
+    if (y1 > rows) y1 = rows;
+    if (x1 > W) x1 = W;
+    const size_t n = (y1 - y0) * (size_t)(x1 - x0);
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out);
+    hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out,
+                       y0, y1, x0, x1);
     return hipGetLastError();
 }
 

@@ -99,17 +99,6 @@ __device__ __forceinline__ bool nms_higher(const float* __restrict__ score, cons
     if (st == ST_NONE || st == ST_SUPPRESSED) return false;
     return prio_key(score[q], q) > kp;
 }
-// append to a device list: one atomic per wave
-__device__ __forceinline__ void list_append(bool pred, uint32_t v, uint32_t* __restrict__ list, unsigned int* cnt) {
-    const unsigned long long m = __ballot(pred);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned int pos = 0;
-        if (lane == __ffsll((long long)m) - 1) pos = atomicAdd(cnt, (unsigned int)__popcll(m));
-        pos = __shfl(pos, __ffsll((long long)m) - 1, 64);
-        if (pred) list[pos + __popcll(m & ((1ull << lane) - 1ull))] = v;
-    }
-}
 // ---- sweep, phase A (one THREAD per still-undecided candidate): probe only the nearest cells of the suppressor set (the
 // 5 x 5 neighbourhood clipped to the disk / the +-1 cube clipped to the ball, nearest first).  Every candidate that is still
 // undecided goes to the next sweep's list; one that is also the best of its neighbourhood goes to the verify list.  In a dense

@@ -55,6 +55,8 @@ static const bool g_exact_fp32 = getenv("TPZ_EXACT_FP32") != nullptr;
 // TPZ_NO_ISSUER=1: every wave issues its own share of the per-step LDS-DMA (A/B switch for tuning, see launch_split)
 static const bool g_no_issuer = getenv("TPZ_NO_ISSUER") != nullptr;
 static const bool g_no_lanes = getenv("TPZ_NO_LANES") != nullptr;      // patches / tiles of an image on one stream only
+// TPZ_NO_ROI=1: every layer of a patch computes its whole tensor (A/B switch; see need_regions)
+static const bool g_no_roi = getenv("TPZ_NO_ROI") != nullptr;
 
 #ifndef TPZ_N_LANES
 #define TPZ_N_LANES 2
@@ -102,6 +104,7 @@ struct tpz_ctx {
     double* lanes_saved_part = nullptr;
     bool lanes_on = false;
     bool lanes_enabled = !g_no_lanes;         // tpz_ctx_set_lanes
+    bool roi_enabled = !g_no_roi;             // tpz_ctx_set_roi: patches compute only what their kept centre depends on
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
@@ -338,7 +341,20 @@ struct tpz_model {
     long long n_split = 0, n_fallback = 0;
 };
 
+// a rectangle of a 2-D tensor; on = false: the whole tensor
+struct Rect {
+    int y0 = 0, x0 = 0, y1 = 0, x1 = 0;
+    bool on = false;
+    void unite(const Rect& r) {
+        if (!r.on) return;
+        if (!on) { *this = r; return; }
+        y0 = std::min(y0, r.y0); x0 = std::min(x0, r.x0); y1 = std::max(y1, r.y1); x1 = std::max(x1, r.x1);
+    }
+    long long area() const { return (long long)(y1 - y0) * (x1 - x0); }
+};
+
 struct Slot {
+    Rect need;                // the part of the tensor that anything reads (need_regions); the producer computes just that
     float* p = nullptr;
     int C = 0, D = 1, H = 0, W = 0;
     long long cs = 0, ps = 0;
@@ -997,6 +1013,19 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
 
 static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops);
 
+// window of a launch from the part of the layer's tensor that is needed (`need` in the tensor's coordinates, `scale` = 2 for the
+// low-resolution lattice of a per-parity / sub-pixel launch, `grow_x` extra columns at the right: the column kernel of a last
+// conv); flops are scaled by the fraction of the lattice that is computed
+static void set_window(SplitArgs& a, const Rect& need, int scale = 1, int grow_x = 0) {
+    if (!need.on) return;
+    a.wy0 = need.y0 / scale; a.wx0 = need.x0 / scale;
+    a.wy1 = std::min(a.Hout, (need.y1 + scale - 1) / scale);
+    a.wx1 = std::min(a.Wout, (need.x1 + scale - 1) / scale + grow_x);
+    a.wy1 = std::max(a.wy1, a.wy0 + 1); a.wx1 = std::max(a.wx1, a.wx0 + 1);
+    a.wy1 = -a.wy1;            // (marks the window as set: launch_split flips it back)
+}
+
+
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
 static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst,
                           const Slot* s2 = nullptr, bool pooled = false) {
@@ -1047,12 +1076,19 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
         a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = 1; a.ooz = 0;
     }
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * a.Hout * a.Wout;
+    set_window(a, dst.need);           // (a pooled dst keeps its need in the coordinates of the un-pooled conv output)
     return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
 
 static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops) {
-    a.tiles_x = (a.Wout + ks.TW - 1) / ks.TW;
-    a.tiles_y = (a.Hout + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
+    if (a.wy1 < 0) {
+        a.wy1 = -a.wy1;
+        flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
+    } else {
+        a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout;
+    }
+    a.tiles_x = (a.wx1 - a.wx0 + ks.TW - 1) / ks.TW;
+    a.tiles_y = (a.wy1 - a.wy0 + ks.TH * ks.D - 1) / (ks.TH * ks.D) * ks.D;
     a.xcd_swizzle = 1;
     a.issuer_half = ks.WAVES == 8 && ks.MT >= 96 && !g_no_issuer;   // -3 .. -4 % on the 128-channel tiles, nothing at 64 (tools/split_ablate.hip)
     if (a.KZ < 1) { a.KZ = 1; a.pad_z = 0; a.Din = a.Dout = a.Dfull = a.Dres = 1; a.ooz = 0; }     // 2-D launch
@@ -1112,6 +1148,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.n_chunks = sp.n_chunks_low;
         a.cog_inner = 1;
         const double fl = 2.0 * L.cout * (ph.c1 * 9.0 * 4.0 + 25.0 * 4.0) * (double)s1.H * s1.W;
+        set_window(a, dst.need, 2);
         const int rc = launch_split(ctx, *sp.ks_sub, a, sp.n_cog_sub, fl);
         pool_release(ctx, X);
         return rc;
@@ -1169,6 +1206,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.n_chunks = sp.n_chunks_skip;
         a.cog_inner = 1;
         const double fl = 2.0 * L.cout * ph.c2 * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+        set_window(a, dst.need);       // (even-aligned by need_regions: the parity launch below adds itself in place)
         if (launch_split(ctx, *sp.ks_skip, a, sp.n_cog_skip, fl)) return 1;
     }
     // ---- every output parity over the low-resolution source in one launch, added in place, then the activation
@@ -1211,6 +1249,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.cog_inner = 1;
         const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W * (1 << L.dims);
         const SplitKernelInfo& kk = sp.ks_sub ? *sp.ks_sub : (sp.low_with_skip ? *sp.ks_low_plain : *sp.ks_low);
+        set_window(a, dst.need, 2);
         const int rc = launch_split(ctx, kk, a, sp.ks_sub ? sp.n_cog_sub : sp.n_cog_low, fl);
         if (Xs2d) pool_release(ctx, Xs2d);
         if (rc) return 1;
@@ -1253,6 +1292,7 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = 1;
     const double fl = 2.0 * L.cout * std::pow((double)L.k, L.dims) * (double)dst.D * Hc * Wc;
+    set_window(a, dst.need);
     const int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
     pool_release(ctx, X);
     return rc;
@@ -1286,10 +1326,14 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = 1;
     const double fl = 2.0 * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
+    const Rect& w = dst.need;
+    set_window(a, w, 1, 2 * L.pad);       // Y columns x .. x + k - 1 feed output column x
     int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
     if (!rc) {
         prof_begin(ctx, 2, 0);
-        hipError_t e = launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream);
+        hipError_t e = w.on ? launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out,
+                                              ctx->stream, (size_t)w.y0, (size_t)w.y1, w.x0, w.x1)
+                            : launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream);
         prof_end(ctx);
         if (e != hipSuccess) rc = fail(ctx, "shiftsum failed: %s", hipGetErrorString(e));
     }
@@ -1375,10 +1419,105 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
 // runs the layer program.  `slots` holds preset external slots (at least slot 0); the dst of the last
 // layer is written to d_out (dense).  d_nrm != nullptr: slot 0 is normalised on load wherever it is read
 // and the output is un-normalised (Denoise._denoise, topaz/denoise.py:283-295).
-static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, const float* d_nrm, bool split = false) {
+// PyTorch 'nearest' source index exactly as the kernels compute it (conv_mfma.h nearest_src)
+static int nearest_src_host(int dst, int in_sz, int out_sz) {
+    if (in_sz == out_sz) return dst;
+    const float scale = (float)in_sz / (float)out_sz;
+    const int v = (int)floorf((float)dst * scale);
+    return v < in_sz - 1 ? v : in_sz - 1;
+}
+
+// Which part of every slot's tensor do the pixels `keep` of the program's output depend on?  (2-D programs on the 2xf16
+// kernels.)  A patched denoise keeps only the centre of each patch (denoise.py:299-323: patch_size pixels of a patch_size +
+// 2*padding tile; CLI default 1024 of 2024), and the U-Net's receptive field (~230 pixels) is far smaller than the default
+// padding (500): most of what the full-size layers of a patch compute is thrown away.  Walking the layer list backwards from
+// `keep` -- a conv needs its window grown by the padding, a 2x2 max-pool twice the window, a nearest-upsampled source the
+// window mapped through the same index formula the kernel uses -- gives every layer the rectangle it has to produce; the
+// launches cover just that (SplitArgs::wy0..wx1).  Nothing else changes: the tensors keep their full-size layout and
+// coordinates, every kept pixel is computed by the same instructions on the same operands as before (bit-identical output,
+// tests/test_gpu_denoise.py), the statistics of the normalisation are still those of the whole padded patch.
+// Returns an empty vector when the program cannot be windowed (3-D, a layer on an fp32 kernel, an op it does not know).
+static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const Rect& keep, bool split) {
+    const int nl = (int)m->layers.size();
+    std::vector<Rect> need;
+    if (!split || !keep.on || !m->ctx->roi_enabled || nl == 0) return need;
+    // shapes of all slots
+    std::vector<int> Hs(m->n_slots, 0), Ws(m->n_slots, 0);
+    Hs[0] = H0; Ws[0] = W0;
+    for (int i = 0; i < nl; ++i) {
+        const LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        if (L.dims != 2) return need;
+        if (L.op == TPZ_OP_CONV) {
+            const bool windowed = rt.ks || rt.ks_last || (rt.ks_stem && L.src == 0) || (rt.sphase.valid && !rt.sphase.ki_skip_stem);
+            if (!windowed) return need;
+            const int g = L.src2 >= 0 ? L.src2 : L.src, span = L.dil * (L.k - 1);
+            Hs[L.dst] = Hs[g] + 2 * L.pad - span; Ws[L.dst] = Ws[g] + 2 * L.pad - span;
+        } else if (L.op == TPZ_OP_MAXPOOL2) {
+            Hs[L.dst] = Hs[L.src] / 2; Ws[L.dst] = Ws[L.src] / 2;
+        } else if (L.op == TPZ_OP_MAXPOOL) {
+            Hs[L.dst] = Hs[L.src] - L.dil * (L.k - 1); Ws[L.dst] = Ws[L.src] - L.dil * (L.k - 1);
+        } else {
+            return need;
+        }
+        if (Hs[L.dst] < 1 || Ws[L.dst] < 1) return need;
+    }
+    need.assign(m->n_slots, Rect());
+    auto clip = [&](Rect r, int slot) {
+        r.y0 = std::max(0, r.y0); r.x0 = std::max(0, r.x0);
+        r.y1 = std::min(Hs[slot], r.y1); r.x1 = std::min(Ws[slot], r.x1);
+        r.on = true;
+        return r;
+    };
+    need[m->layers[nl - 1].L.dst] = clip(keep, m->layers[nl - 1].L.dst);
+    for (int i = nl - 1; i >= 0; --i) {
+        const tpz_layer& L = m->layers[i].L;
+        Rect R = need[L.dst];
+        if (!R.on) { need.clear(); return need; }            // a tensor nobody reads: leave the program alone
+        if (L.op == TPZ_OP_CONV) {
+            // launch windows start and end on even pixels: the per-parity kernels work on the half-resolution lattice, a
+            // fused max-pool pairs rows and columns
+            R.y0 &= ~1; R.x0 &= ~1;
+            R.y1 = std::min(Hs[L.dst], (R.y1 + 1) & ~1); R.x1 = std::min(Ws[L.dst], (R.x1 + 1) & ~1);
+            need[L.dst] = R;
+            const int g = L.src2 >= 0 ? L.src2 : L.src, span = L.dil * (L.k - 1);
+            Rect G;                                           // in the coordinates of the (upsampled) input grid
+            G.y0 = R.y0 - L.pad; G.x0 = R.x0 - L.pad; G.y1 = R.y1 - L.pad + span; G.x1 = R.x1 - L.pad + span;
+            G = clip(G, g);
+            if (L.src2 >= 0) {
+                need[L.src2].unite(G);
+                Rect S;                                       // the first source, nearest-upsampled to the grid of the second
+                S.y0 = nearest_src_host(G.y0, Hs[L.src], Hs[g]); S.y1 = nearest_src_host(G.y1 - 1, Hs[L.src], Hs[g]) + 1;
+                S.x0 = nearest_src_host(G.x0, Ws[L.src], Ws[g]); S.x1 = nearest_src_host(G.x1 - 1, Ws[L.src], Ws[g]) + 1;
+                need[L.src].unite(clip(S, L.src));
+            } else {
+                need[L.src].unite(G);
+            }
+            if (L.res >= 0) {
+                Rect Q = R;
+                Q.y0 += L.res_crop; Q.y1 += L.res_crop; Q.x0 += L.res_crop; Q.x1 += L.res_crop;
+                need[L.res].unite(clip(Q, L.res));
+            }
+        } else if (L.op == TPZ_OP_MAXPOOL2) {
+            Rect Q;
+            Q.y0 = 2 * R.y0; Q.x0 = 2 * R.x0; Q.y1 = 2 * R.y1; Q.x1 = 2 * R.x1;
+            need[L.src].unite(clip(Q, L.src));
+        } else {
+            Rect Q = R;
+            Q.y1 += L.dil * (L.k - 1); Q.x1 += L.dil * (L.k - 1);
+            need[L.src].unite(clip(Q, L.src));
+        }
+    }
+    return need;
+}
+
+static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, const float* d_nrm, bool split = false,
+                       const Rect* keep = nullptr) {
     tpz_ctx* ctx = m->ctx;
     const int nl = (int)m->layers.size();
     slots.resize(std::max<size_t>(slots.size(), (size_t)m->n_slots));
+    std::vector<Rect> need;
+    if (keep && slots[0].set && slots[0].D == 1) need = need_regions(m, slots[0].H, slots[0].W, *keep, split);
     int rc = 0;
     for (int i = 0; i < nl && rc == 0; ++i) {
         const LayerRT& rt = m->layers[i];
@@ -1421,6 +1560,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
             if (fuse_pool && (Hd < 1 || Wd < 1)) { rc = fail(ctx, "layer %d: input too small to pool", i + 1); break; }
             set_dense(dst, p, Co, Do, Hd, Wd);
+            dst.need = need.empty() ? Rect() : need[L.dst];
             dst.split = split_dst;
             dst.pooled = fuse_pool;
             dst.alt = nullptr;
@@ -1445,6 +1585,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
         } else if (L.op == TPZ_OP_MAXPOOL2 && s1.pooled) {
             // already pooled by the producing conv: the slot changes hands
             dst = s1;
+            dst.need = need.empty() ? Rect() : need[L.dst];
             dst.pooled = false;
             slots[L.src].owned = false;
             slots[L.src].alt = nullptr;
@@ -1707,6 +1848,12 @@ int tpz_ctx_set_lanes(tpz_ctx* ctx, int on) {
     return 0;
 }
 
+int tpz_ctx_set_roi(tpz_ctx* ctx, int on) {
+    if (!ctx) return 1;
+    ctx->roi_enabled = on != 0;
+    return 0;
+}
+
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     ctx->exact = (on != 0) || g_exact_fp32;
@@ -1787,7 +1934,7 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
 // Denoise._denoise on a (strided) region: mean / unbiased std -> normalise -> network -> un-normalise.
 // mode 1: plain; mode 2: the un-normalisation also applies the volume's std*y+mu with g = {mu, std}.
 static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int mode = 1,
-                          const float* d_g = nullptr, bool split = false) {
+                          const float* d_g = nullptr, bool split = false, const Rect* keep = nullptr) {
     tpz_ctx* ctx = m->ctx;
     float* nrm = next_nrm(ctx);
     prof_begin(ctx, 2, 0);
@@ -1805,7 +1952,7 @@ static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, in
     if (e != hipSuccess) { pool_release(ctx, xn); return fail(ctx, "affine_dev failed: %s", hipGetErrorString(e)); }
     std::vector<Slot> slots(m->n_slots);
     set_dense(slots[0], xn, 1, view.D, view.H, view.W);
-    const int rc = run_program(m, slots, d_out_dense, nrm, split);
+    const int rc = run_program(m, slots, d_out_dense, nrm, split, keep);
     pool_release(ctx, xn);
     return rc;
 }
@@ -1834,10 +1981,12 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
             v.cs = v.ps;
             float* tmp = (float*)pool_alloc(ctx, (size_t)ph * pw * sizeof(float));
             if (!tmp) { rc_all = fail(ctx, "out of device memory"); break; }
-            int rc = denoise_region(m, v, tmp, 1, nullptr, split);
+            const int oi = i - si, oj = j - sj;
+            const int ch = std::min(patch, std::min(H - i, ph - oi)), cw = std::min(patch, std::min(W - j, pw - oj));
+            Rect keep;                     // the pixels of this patch that reach the output image (denoise.py:321)
+            keep.y0 = oi; keep.x0 = oj; keep.y1 = oi + ch; keep.x1 = oj + cw; keep.on = true;
+            int rc = denoise_region(m, v, tmp, 1, nullptr, split, &keep);
             if (rc == 0) {
-                const int oi = i - si, oj = j - sj;
-                const int ch = std::min(patch, std::min(H - i, ph - oi)), cw = std::min(patch, std::min(W - j, pw - oj));
                 prof_begin(ctx, 2, 0);
                 hipError_t e = launch_copy_box(tmp + (size_t)oi * pw + oj, 0, pw, d_out + (size_t)i * W + j, 0, W, 1, ch,
                                                cw, ctx->stream);

@@ -74,6 +74,10 @@ class Context:
         """patch lanes of tpz_denoise_2d / _3d (two auxiliary streams); off: every launch on the ctx stream"""
         check(self.lib.tpz_ctx_set_lanes(self.handle, 1 if on else 0), self.handle)
 
+    def set_roi(self, on: bool = True) -> None:
+        """patch windows of tpz_denoise_2d: each layer of a patch computes only what the kept centre depends on (default on)"""
+        check(self.lib.tpz_ctx_set_roi(self.handle, 1 if on else 0), self.handle)
+
     def prof_get(self, cls: int) -> Tuple[float, int, float]:
         ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
         check(self.lib.tpz_prof_get(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)), self.handle)
