@@ -106,6 +106,7 @@ struct SplitCfg {
     // 8 waves: one workgroup per CU (the big dilated tiles need most of the LDS); 4 waves: two per CU, so that
     // one workgroup's prologue / epilogue / barrier waits overlap the other's MFMAs (small-halo, short-K layers)
     static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_, WGS_PER_CU = WAVES_ == 8 ? 1 : 2;
+    static constexpr bool UNIFORM_DMA = (MT_ >= 128 && WAVES_ == 8);    // how the LDS-DMA is issued (see issue_input)
     static constexpr int MW = MT / 16;
     static constexpr int RPW = TH / WAVES;
     static constexpr int NFC = TW / 16;
@@ -274,9 +275,14 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
 
-    // One LDS-DMA instruction (16 bytes per lane, 1 KiB per wave) from a PER-LANE source address: lanes whose cell lies
-    // outside the image (or past the last channel) read the zero block instead, a lane of the plane-stacked 3-D mode picks
-    // its own source tensor -- no divergent paths around the instruction, and M0 is the compiler's to set.
+    // One LDS-DMA instruction moves 16 bytes per lane, 1 KiB per wave.  Two ways to issue it:
+    //  * per-lane 64-bit source address through the builtin (glds16): lanes whose cell lies outside the image (or past the last
+    //    channel) point at the zero block, a lane of the plane-stacked 3-D mode at its own source tensor -- one instruction per
+    //    piece, no divergent paths, M0 set by the compiler.  Fewer instructions: what the narrow tiles, bound by the issue of
+    //    everything that is not an MFMA, want (-2 ... -5 %).
+    //  * wave-uniform base + 32-bit lane offset in inline asm (glds_b128), with separate paths for waves that hold out-of-image
+    //    lanes: no 64-bit address arithmetic in the vector unit.  The 128-channel 8-wave tiles run at 256 VGPRs and lose 1.5 %
+    //    with the per-lane form (same-box A/B of the fused-head kernel), so they keep this one (SplitCfg::UNIFORM_DMA).
     auto glds16 = [&](const void* src, unsigned lds_addr) {
         __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
                                          (__attribute__((address_space(3))) void*)(size_t)lds_addr, 16, 0, 0);
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             size_t lo_delta = ((ABL & 8192) ? (size_t)0x20000 : second ? plane2 : plane1) * 16;      // bytes from a hi cell to its lo cell
             unsigned off = (ABL & 4096) ? (unsigned)g * 16u : lds_tab[g];      // (ABL 4096: no table, contiguous source)
             if constexpr ((ABL & 8192) != 0) off = off == OOB ? off : (off & 0x1ffff0u);
-            const unsigned char* src = bhi;
+            bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
             if (!vol) {
                 if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
             } else {
@@ -304,17 +310,39 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int iz = oz + kz - pad_z;
                 if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
                 else if (off != OOB) {
-                    const bool lane2 = c >= a.cells_in1;             // this lane's cell comes from `in2`
+                    lane2 = c >= a.cells_in1;
                     off += (unsigned)((((size_t)(lane2 ? c - a.cells_in1 : c) * a.Din + iz) * a.Hin) * a.Win * 16);
-                    if (lane2) { src = reinterpret_cast<const unsigned char*>(a.in2); lo_delta = plane2 * 16; }
                 }
             }
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
-            const bool oob = off == OOB;
-            const unsigned char* shi = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off;
-            const unsigned char* slo = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off + lo_delta;
-            glds16(shi, dst);
-            glds16(slo, dst + C::PLANE_BYTES);
+            if constexpr (C::UNIFORM_DMA) {
+                const void* blo = bhi + lo_delta;
+                if (!__any(off == OOB || lane2)) {
+                    glds_b128(off, bhi, dst);
+                    glds_b128(off, blo, dst + C::PLANE_BYTES);
+                } else {
+                    if (off == OOB) {
+                        glds_b128(0u, zsrc, dst);
+                        glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
+                    } else if (lane2) {
+                        const void* b2 = uniform_ptr(a.in2);
+                        const void* b2lo = uniform_ptr(a.in2 + plane2);
+                        glds_b128(off, b2, dst);
+                        glds_b128(off, b2lo, dst + C::PLANE_BYTES);
+                    } else {
+                        glds_b128(off, bhi, dst);
+                        glds_b128(off, blo, dst + C::PLANE_BYTES);
+                    }
+                }
+            } else {
+                const unsigned char* src = bhi;
+                if (lane2) { src = reinterpret_cast<const unsigned char*>(a.in2); lo_delta = plane2 * 16; }
+                const bool oob = off == OOB;
+                const unsigned char* shi = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off;
+                const unsigned char* slo = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off + lo_delta;
+                glds16(shi, dst);
+                glds16(slo, dst + C::PLANE_BYTES);
+            }
         }
     };
     // weights of stage `stg` (its steps that exist: `bytes` = min(SPS, steps left) * W_STEP_BYTES) -> weight buffer `buf`
@@ -323,8 +351,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STAGE_BYTES + wave * 1024));
 #pragma unroll
         for (int i = 0; i < C::WR; ++i)
-            if ((i * C::WAVES + wave) * 1024 < bytes)                  // whole waves (1 KiB each)
-                glds16(base + (unsigned)(i * C::THREADS + tid) * 16u, dst + i * C::THREADS * 16);
+            if ((i * C::WAVES + wave) * 1024 < bytes) {                // whole waves (1 KiB each)
+                if constexpr (C::UNIFORM_DMA) glds_b128((unsigned)(i * C::THREADS + tid) * 16u, base, dst + i * C::THREADS * 16);
+                else glds16(base + (unsigned)(i * C::THREADS + tid) * 16u, dst + i * C::THREADS * 16);
+            }
     };
 
     // per-lane LDS read bases (bytes)
