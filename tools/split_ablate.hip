@@ -166,6 +166,14 @@ int main(int argc, char** argv) {
         quick<SplitCfg<1, 1, 128, 8, 16, 4, 4, 1, 1>, EPI_PLAIN>("K1 MT128 4w 8x16 CC4", 64, 128, 4136);
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "d2") {
+        // 64-channel dilation-2 layers of ResNet8's first block: 8 waves (one workgroup per CU) vs 4 waves (two per CU)
+        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w S=2 (current)", 64, 64, 2048);
+        quick<SplitCfg<3, 2, 64, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D2 MT64 4w S=1", 64, 64, 2048);
+        quick<SplitCfg<3, 2, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D2 MT64 8w S=2 RES (current)", 64, 64, 2048);
+        quick<SplitCfg<3, 2, 64, 8, 32, 2, 4, 3, 1>, EPI_RES>("K3 D2 MT64 4w S=1 RES", 64, 64, 2048);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "lat") {
         // is the per-step DMA cost its ISSUE or waiting for its ARRIVAL?  (round 2: the issue -- never waiting for the
         // data changes nothing; a dedicated producer wave issuing all of it was 7 - 30 % SLOWER: one wave sustains about
