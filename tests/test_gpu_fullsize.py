@@ -107,6 +107,13 @@ def test_bench_unet_nf48_4096_default_patching_vs_oracle_patches(gpu_ctx):
         ref = ref[i - si:i - si + 1024, j - sj:j - sj + 1024]
         e = _abs(y[i:i + 1024, j:j + 1024], ref)
         assert e <= ATOL, (i, j, e)
+    # the same micrograph with every tensor of every patch computed in full (patch windows off): not one bit differs
+    try:
+        gpu_ctx.set_roi(False)
+        y_full = d.denoise_device(torch.from_numpy(x).cuda(), 1024, 500).cpu().numpy()
+    finally:
+        gpu_ctx.set_roi(True)
+    assert np.array_equal(y, y_full)
 
 
 def _picks_equivalent(s, c, so, co, ref_map, r, tol, thr=-6.0):
