@@ -42,6 +42,23 @@ def test_seeded_vs_reference_golden(gpu_ctx, name):
     assert np.abs(y - z['y0']).max() <= ATOL
 
 
+def test_prelu_slopes_outside_unit_interval(gpu_ctx):
+    """conv31 (BasicConv: PReLU after every conv) with learned slopes the 2xf16 epilogue's max(v, slope * v) cannot express
+    (> 1) next to ones it can (negative, 0, 1): a layer with slope > 1 must stay on its fp32 kernel; result vs the oracle"""
+    from topaz_amd.model.classifier import LinearClassifier
+    z = load_golden('score_conv31_u32')
+    sd = dict(golden_sd(z))
+    acts = sorted(k for k in sd if k.startswith('features.features.') and np.asarray(sd[k]).size == 1)
+    assert len(acts) == 3
+    x = z['x0']
+    for slopes in ((1.7, -0.4, 0.0), (0.3, 2.5, 1.0), (1.0001, 0.999, 3.0)):
+        for k, v in zip(acts, slopes):
+            sd[k] = np.full_like(np.asarray(sd[k]), v)
+        ref = oscoring.score('conv31', sd, x)
+        y = _score(LinearClassifier('conv31', sd), x)
+        assert np.abs(y - ref).max() <= ATOL * max(1.0, float(np.abs(ref).max()) / 20), slopes
+
+
 @pytest.mark.parametrize('arch,units', [('resnet8', 64), ('resnet16', 64), ('resnet8', 32)])
 def test_seeded_vs_oracle_512(gpu_ctx, arch, units):
     """the CLI-default widths (u64, blobs missing upstream) with seeded weights, 512x384 image"""

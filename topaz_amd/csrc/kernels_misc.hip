@@ -557,16 +557,20 @@ hipError_t launch_gmm_pass(const float* x, size_t n, int mode, const double* d_p
 // shiftsum: out[z][y][x] = sum_v Y[v][z][y][x + v] + bias (then the un-normalisation): the kx taps of a
 // 1-output-channel conv were computed as K virtual output channels over W + 2*pad columns.
 // ------------------------------------------------------------------------------------------
+// (only rows [r0, r1) x columns [x0, x1) are produced: what the window of the stem conv reads, runtime.hip)
 __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restrict__ in, uint4* __restrict__ out,
                                                            int ncell, int K, int pad, size_t rows, int W, int Wo,
-                                                           unsigned* flag) {
+                                                           unsigned* flag, size_t r0, size_t r1, int x0, int x1) {
     const size_t n = (size_t)ncell * rows * Wo;
+    const int nx = x1 - x0;
+    const size_t nr = r1 - r0, nw = (size_t)ncell * nr * nx;
     bool big = false;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % Wo);
-        const size_t t = i / Wo;
-        const size_t row = t % rows;
-        const int jc = (int)(t / rows);
+    for (size_t iw = blockIdx.x * (size_t)blockDim.x + threadIdx.x; iw < nw; iw += (size_t)gridDim.x * blockDim.x) {
+        const int x = x0 + (int)(iw % nx);
+        const size_t t = iw / nx;
+        const size_t row = r0 + t % nr;
+        const int jc = (int)(t / nr);
+        const size_t i = ((size_t)jc * rows + row) * Wo + x;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -603,11 +607,14 @@ __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__
 }
 
 hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, unsigned* flag,
-                               hipStream_t s) {
+                               hipStream_t s, size_t r0, size_t r1, int x0, int x1) {
     const int ncell = (K + 7) / 8;
-    const size_t n = (size_t)ncell * rows * Wo;
+    if (r1 > rows) r1 = rows;
+    if (x1 > Wo) x1 = Wo;
+    const size_t n = (size_t)ncell * (r1 - r0) * (size_t)(x1 - x0);
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(shiftx_split_kernel, dim3(blocks), dim3(256), 0, s, in, (uint4*)out, ncell, K, pad, rows, W, Wo, flag);
+    hipLaunchKernelGGL(shiftx_split_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, in, (uint4*)out, ncell, K, pad, rows, W,
+                       Wo, flag, r0, r1, x0, x1);
     return hipGetLastError();
 }
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,

@@ -1269,7 +1269,12 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * Wc * sizeof(float));
     if (!X) return fail(ctx, "out of device memory");
     prof_begin(ctx, 2, 0);
-    hipError_t e = launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream);
+    // (2-D with a window: only the rows and columns the windowed conv reads -- output row y reads input rows y - pad .. y + pad)
+    const Rect& w = dst.need;
+    hipError_t e = (w.on && L.dims == 2)
+        ? launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream, (size_t)std::max(0, w.y0 - L.pad),
+                              (size_t)std::min(s1.H, w.y1 + L.pad), w.x0, std::min(Wc, (w.x1 + 1) & ~1))
+        : launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream);
     prof_end(ctx);
     if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "shiftx failed: %s", hipGetErrorString(e)); }
     SplitArgs a;
@@ -1873,6 +1878,7 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
                       const float* h_post_scale, const float* h_post_shift, const float* h_head_w, float head_b,
                       float* d_out, int* overflow) {
     if (!ctx || !d_in || !h_w || !d_out) return fail(ctx, "tpz_conv_split_2d: NULL argument");
+    if (slope > 1.f) return fail(ctx, "tpz_conv_split_2d: the 2xf16 epilogue applies max(v, slope * v): slope must be <= 1 (%g)", slope);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int epi = EPI_PLAIN;
     if (h_head_w) epi = EPI_HEAD;
