@@ -100,6 +100,10 @@ class TopazHipError(RuntimeError):
 def load_library(path: str | None = None) -> C.CDLL:
     """dlopen libtopaz_hip.so and declare every prototype.  Raises if the library is missing."""
     global _lib
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64), and the two copies in one process do not share
+    # devices -- loaded the other way round (library, then torch) tpz_ctx_create finds no device.  With torch's runtime
+    # already mapped, the library's libamdhip64 dependency resolves to it.
+    import torch  # noqa: F401
     with _lock:
         if _lib is not None and path is None:
             return _lib
