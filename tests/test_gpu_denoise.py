@@ -176,6 +176,27 @@ def test_patch_windows_are_bit_identical(gpu_ctx, case):
         assert eligible and split_runs >= 2
 
 
+def test_patch_windows_random_geometries(gpu_ctx):
+    """seeded sweep of image sizes, patch sizes and paddings (odd sizes, paddings below and above the receptive field,
+    patches that do not divide the image): windowed and full computation agree bit for bit"""
+    from topaz_amd.denoise import Denoise
+    rs = np.random.RandomState(4242)
+    nets = [Denoise('unet-v0.2.1'), Denoise('unet-small')]
+    try:
+        for it in range(10):
+            d = nets[it % 2]
+            H, W = int(rs.randint(180, 900)), int(rs.randint(180, 900))
+            patch, pad = int(rs.randint(48, 320)), int(rs.randint(8, 260))
+            x = (rs.randn(H, W) * 2 - 0.5).astype(np.float32)
+            gpu_ctx.set_roi(False)
+            full = d.denoise(x, patch, pad)
+            gpu_ctx.set_roi(True)
+            win = d.denoise(x, patch, pad)
+            assert np.array_equal(full, win), (it, H, W, patch, pad)
+    finally:
+        gpu_ctx.set_roi(True)
+
+
 def test_edge_cases(gpu_ctx):
     from topaz_amd._lib import TopazHipError
     from topaz_amd.denoise import Denoise
