@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import pickle
 from collections import OrderedDict
-from typing import Tuple
 
 import torch
 

@@ -6,7 +6,7 @@ torch.distributed.  All arithmetic of the hot path happens inside libtopaz_hip.s
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
