@@ -92,6 +92,12 @@ struct SplitArgs {
     // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
     // centre, so every layer computes only the part of its tensor that the kept pixels depend on (runtime.hip, need_regions).
     int wy0, wx0, wy1, wx1;
+    // FOLDED 1x1 projection (ResidA: y = conv1(t) + proj(h), resnet.py:185-202): the last fold_cells cells of the K loop come
+    // from `in2` = h with ONE tap each -- the centre tap of the tile layout, read at (row + in2_oy, column + in2_ox) of an
+    // in2_H x in2_W tensor -- instead of a separate 1x1 pass that writes a 128-channel residual tensor and reads it back
+    // (13 GB per micrograph).  In the slot stream each folded chunk (CC = 2 cells) is one step: slots (centre tap, cell 0 / 1)
+    // and (next tap, cell 0 / 1), the latter with zero weights.  Kernels with one step per stage only (SPS == 1).
+    int fold_cells, fold_tap, in2_H, in2_W, in2_oy, in2_ox;
 };
 
 struct SplitSlot {
@@ -247,7 +253,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     // (tid and the sizes nearest_src() divides are passed in: the co-group loop hands over opaque copies, so that nothing of this prologue is
     // hoisted out of that loop and kept in registers across the K loop)
     auto compute_offsets = [&](bool second, int tid, int H1, int W1, int Hup, int Wup) {
-        const int Hs = second ? a.Hin : H1, Ws = second ? a.Win : W1;
+        const bool fold2 = second && a.fold_cells > 0;       // the folded source has its own size and origin
+        const int Hs = fold2 ? a.in2_H : second ? a.Hin : H1, Ws = fold2 ? a.in2_W : second ? a.Win : W1;
+        const int Hv = fold2 ? a.in2_H : a.Hin, Wv = fold2 ? a.in2_W : a.Win;
 #pragma unroll 1
         for (int i = 0; i < C::NR; ++i) {
             const int g = i * C::THREADS + tid;
@@ -255,9 +263,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int c = g / C::CELL_STRIDE;
                 const int rem = g - c * C::CELL_STRIDE;
                 const int r = rem / C::ITW, x = rem - r * C::ITW;
-                const int gy = ybase + r * D, gx = xbase + x;
+                const int gy = ybase + r * D + (fold2 ? a.in2_oy : 0), gx = xbase + x + (fold2 ? a.in2_ox : 0);
                 unsigned off = OOB;
-                if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) {
+                if ((unsigned)gy < (unsigned)Hv && (unsigned)gx < (unsigned)Wv) {
                     int sy = gy, sx = gx;
                     if (!second && ups) { sy = nearest_src(gy, H1, Hup); sx = nearest_src(gx, W1, Wup); }
                     // 3-D: the in-plane part only; the (cell, plane) part is added per chunk in issue_input
@@ -271,7 +279,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     // (plane-stacked 3-D: the source is chosen per cell in issue_input, chunks never switch)
     const int chunks1 = (a.in2 && !vol) ? a.cells_in1 / C::CC : a.n_chunks;
     const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1 * (vol ? a.Din : 1);   // cells per plane of `in`
-    const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * a.Hin * a.Win * (vol ? a.Din : 1);   // ... of `in2`
+    const size_t hw2 = a.fold_cells > 0 ? (size_t)a.in2_H * a.in2_W : (size_t)a.Hin * a.Win;      // one cell plane of `in2`
+    const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * hw2 * (vol ? a.Din : 1);           // ... of `in2`
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
 
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const int g = r * C::THREADS + tid;
         if (g < C::NPC) {
             const bool second = ch >= chunks1;
-            const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * a.Hin * a.Win
+            const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * hw2
                                         : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
             if constexpr ((ABL & 8192) != 0) chunk = a.in;            // (ABL 8192: every tile reads one L2-resident window)
             const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
@@ -366,9 +375,11 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
     bool big = false;
 
-    const int vcells = a.cells_in * (vol ? a.KZ : 1);        // (virtual) cells of the K loop
+    const bool folded = C::CONT && C::SPS == 1 && a.fold_cells > 0;
+    const int vcells = (folded ? a.cells_in1 : a.cells_in) * (vol ? a.KZ : 1);        // (virtual) cells of the K loop (all taps)
     const int n_full = vcells / C::CC, n_rem = vcells - n_full * C::CC;      // full chunks; cells of a short last chunk
-    const int n_stages = C::CONT ? C::cont_stages(vcells) : a.n_chunks * C::NSTEP;
+    const int n_stages_a = C::CONT ? C::cont_stages(vcells) : a.n_chunks * C::NSTEP;
+    const int n_stages = n_stages_a + (folded ? a.fold_cells / C::CC : 0);    // + one step per folded chunk
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
@@ -399,6 +410,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         // LDS address of this lane's B fragments of step st (its slot of the step: tap + cell of the chunk's tile)
         auto b_frag_base = [&](int st, int l4) -> const unsigned char* {
             if constexpr (C::CONT) {
+                if (folded && st >= n_stages_a)       // a folded chunk: the centre tap (and its zero-weight neighbour), cells 0 / 1
+                    return lds + ((chunks1 + st - n_stages_a) & 1) * C::IN_BUF + b_lane + lds_slot[a.fold_tap * C::CC + l4];
                 int G = 4 * st + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
                 if (cg2 >= n_full) {
                     // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond
@@ -448,6 +461,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int gs = (ws + C::SPS - 1) / C::SPS, ge = (we + 1) / C::SPS - 1;
                 r0 = (stage >= gs && stage <= ge) ? stage - gs : C::NR;
                 rstride = ge - gs + 1;
+                if (folded && s >= n_stages_a) {
+                    // a folded chunk lasts one step: the next one is fetched whole during this step
+                    ch = chunks1 + (s - n_stages_a);
+                    pf = ch + 1;
+                    r0 = 0;
+                    rstride = 1;
+                }
             } else {
                 ch = s / C::NSTEP;
                 pf = ch + 1;

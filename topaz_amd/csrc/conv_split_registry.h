@@ -19,7 +19,7 @@ struct SplitKernelInfo {
 };
 
 void register_split(const SplitKernelInfo& info);
-const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0);    // KX = 0: square (KX == K)
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {

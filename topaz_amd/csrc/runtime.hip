@@ -36,11 +36,15 @@ static std::vector<SplitKernelInfo>& split_registry() {
     return r;
 }
 void register_split(const SplitKernelInfo& info) { split_registry().push_back(info); }
-const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX) {
+const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX, int sps) {
     if (KX <= 0) KX = K;
+    // several instantiations of one shape may differ in the steps per stage: the most steps (fewest barriers) unless the
+    // caller needs a particular form (sps > 0: the folded 1x1 projection exists for one-step stages only)
+    const SplitKernelInfo* best = nullptr;
     for (const auto& k : split_registry())
-        if (k.K == K && k.KX == KX && k.D == D && k.MT == MT && k.epi == epi) return &k;
-    return nullptr;
+        if (k.K == K && k.KX == KX && k.D == D && k.MT == MT && k.epi == epi && (sps <= 0 || k.SPS == sps) &&
+            (!best || k.SPS > best->SPS)) best = &k;
+    return best;
 }
 }  // namespace tpz
 
@@ -299,6 +303,15 @@ struct LayerRT {
     const SplitKernelInfo* ks_stem = nullptr;
     const SplitKernelInfo* ks_last = nullptr;
     const SplitKernelInfo* ks_pool = nullptr;  // twin of ks / ks_stem with the following 2x2 max-pool fused (EPI_POOL)
+    // ResidA blocks that change width, y = [bn1](conv1(t) + proj(h)) (resnet.py:185-202): on the 2xf16 path the 1x1 projection is
+    // FOLDED into conv1's K loop (SplitArgs::fold_cells) -- the projection layer is then skipped (folded_into = index of conv1)
+    // and conv1 runs ks_fold (one-step stages, plain epilogue) over its own source + slot fold_src, eval-BN folded into weights
+    int folded_into = -1;
+    int fold_src = -1, fold_cells = 0, f_n_cog = 1, f_n_chunks = 1;
+    const SplitKernelInfo* ks_fold = nullptr;
+    void* d_wfold = nullptr;
+    float* d_wscale_fold = nullptr;
+    float* d_bias_fold = nullptr;
     // 2xf16 twin of the phase decomposition: the skip-source part runs first (stem kernel storing split cells
     // when the skip is the 1-channel image, else a plain split kernel), then one split kernel per output parity
     // adds itself in place through the residual epilogue and applies the activation
@@ -565,15 +578,20 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
 // ---- 2xf16 path (conv_split.h) ---------------------------------------------------------------------
 // weights [cout][cin][k][k] -> per (co-group, chunk, step) blocks  [plane hi|lo][m][lane = kb*16 + i][8 channels]
 // of f16, scaled per output channel by 2^s (max |w| lands in [2^13, 2^14)) so that the lo halves stay normal.
+// wp / cin_b: a 1x1 projection [cout][cin_b] folded in behind the conv's own stages, one step per chunk of its input cells
+// (SplitArgs::fold_cells); mul: per-output-channel factor applied to both weight sets (an eval-BN scale folded into them)
 static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int cout, int cin, int n_cog, int n_chunks,
-                               std::vector<uint16_t>& out, std::vector<float>& wscale_inv) {
+                               std::vector<uint16_t>& out, std::vector<float>& wscale_inv, const float* wp = nullptr,
+                               int cin_b = 0, const float* mul = nullptr) {
     const int K = ki.K, KX = ki.KX, MW = ki.MT / 16;
     const size_t taps = (size_t)K * KX;
     std::vector<float> scale(cout, 1.f);
     wscale_inv.assign(cout, 1.f);
     for (int co = 0; co < cout; ++co) {
         float mx = 0.f;
-        for (size_t i = 0; i < (size_t)cin * taps; ++i) mx = std::max(mx, std::fabs(w[(size_t)co * cin * taps + i]));
+        const float f = mul ? std::fabs(mul[co]) : 1.f;
+        for (size_t i = 0; i < (size_t)cin * taps; ++i) mx = std::max(mx, f * std::fabs(w[(size_t)co * cin * taps + i]));
+        for (int i = 0; wp && i < cin_b; ++i) mx = std::max(mx, f * std::fabs(wp[(size_t)co * cin_b + i]));
         int e = 0;
         if (mx > 0.f && std::isfinite(mx)) e = std::min(60, std::max(-60, (int)std::floor(std::log2(16384.0 / mx))));
         scale[co] = std::ldexp(1.f, e);
@@ -581,12 +599,38 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
     }
     const size_t step_halfs = (size_t)ki.W_STEP_BYTES / 2;
     const int cells = (int)split_cells(cin);
-    const int n_stages = ki.stages(cells);
+    const int n_stages_a = ki.stages(cells);
+    const int n_stages = n_stages_a + (wp ? (int)split_cells(cin_b) / ki.CC : 0);
     const int n_full = cells / ki.CC, n_rem = cells - n_full * ki.CC, taps_n = ki.cont ? ki.Q / ki.CC : 0;
     out.assign((size_t)n_cog * n_stages * step_halfs, 0);
+    auto put = [&](uint16_t* blk, int m, int kb, int i, int j, float v) {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        uint16_t hb, lb;
+        memcpy(&hb, &hi, 2);
+        memcpy(&lb, &lo, 2);
+        const size_t lane = (size_t)kb * 16 + i;
+        blk[((size_t)(0 * MW + m) * 64 + lane) * 8 + j] = hb;
+        blk[((size_t)(1 * MW + m) * 64 + lane) * 8 + j] = lb;
+    };
     for (int cog = 0; cog < n_cog; ++cog)
         for (int st = 0; st < n_stages; ++st) {
             uint16_t* blk = out.data() + ((size_t)cog * n_stages + st) * step_halfs;
+            if (st >= n_stages_a) {
+                // folded projection: slots (centre tap, cell 0 .. CC-1); the slots of the neighbouring tap keep zero weights
+                const int cb = st - n_stages_a;
+                for (int kb = 0; kb < ki.CC; ++kb)
+                    for (int m = 0; m < MW; ++m)
+                        for (int i = 0; i < 16; ++i) {
+                            const int co = cog * ki.MT + m * 16 + i;
+                            if (co >= cout) continue;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ci = (cb * ki.CC + kb) * 8 + j;
+                                if (ci < cin_b) put(blk, m, kb, i, j, wp[(size_t)co * cin_b + ci] * scale[co] * (mul ? mul[co] : 1.f));
+                            }
+                        }
+                continue;
+            }
             for (int kb = 0; kb < 4; ++kb) {
                 // (chunk, tap, cell) of lane group kb in this step
                 int ch;
@@ -615,15 +659,7 @@ static void pack_weights_split(const SplitKernelInfo& ki, const float* w, int co
                         for (int j = 0; j < 8; ++j) {
                             const int ci = (ch * ki.CC + sl.c) * 8 + j;
                             if (ci >= cin) continue;
-                            const float v = w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * KX + sl.kx] * scale[co];
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            uint16_t hb, lb;
-                            memcpy(&hb, &hi, 2);
-                            memcpy(&lb, &lo, 2);
-                            const size_t lane = (size_t)kb * 16 + i;
-                            blk[((size_t)(0 * MW + m) * 64 + lane) * 8 + j] = hb;
-                            blk[((size_t)(1 * MW + m) * 64 + lane) * 8 + j] = lb;
+                            put(blk, m, kb, i, j, w[((size_t)co * cin + ci) * taps + (size_t)sl.ky * KX + sl.kx] * scale[co] * (mul ? mul[co] : 1.f));
                         }
                     }
             }
@@ -936,6 +972,50 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         const SplitKernelInfo* pk = find_split(base->K, base->D, base->MT, EPI_POOL, base->KX);
         if (pk && pk->CC == base->CC && pk->NSTEP == base->NSTEP && pk->cont == base->cont && pk->W_STEP_BYTES == base->W_STEP_BYTES) rt.ks_pool = pk;
     }
+    // ---- fold 1x1 projections into the conv that adds them as its residual
+    static const bool no_fold = getenv("TPZ_NO_FOLD") != nullptr;
+    for (int i = 0; i < nl && !no_fold; ++i) {
+        LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        if (L.op != TPZ_OP_CONV || L.dims != 2 || !rt.ks || L.res < 0 || L.src2 >= 0 || L.head || L.k % 2 == 0) continue;
+        if (rt.ks->epi != EPI_RES && rt.ks->epi != EPI_RES_POST) continue;
+        int j = -1, readers = 0;
+        for (int t = 0; t < nl; ++t) {
+            const tpz_layer& T = m->layers[t].L;
+            if (T.dst == L.res && t < i) j = t;
+            if (T.src == L.res || T.src2 == L.res || T.res == L.res) ++readers;
+        }
+        if (j < 0 || readers != 1) continue;
+        LayerRT& pj = m->layers[j];
+        const tpz_layer& P = pj.L;
+        if (P.op != TPZ_OP_CONV || P.dims != 2 || P.k != 1 || P.pad != 0 || P.slope != 1.f || P.b_off >= 0 || P.res >= 0 ||
+            P.src2 >= 0 || P.head || P.post_scale_off >= 0 || P.cout != L.cout || !pj.ks) continue;
+        const SplitKernelInfo* kf = find_split(L.k, L.dil, rt.ks->MT, EPI_PLAIN, 0, 1);
+        if (!kf || !kf->cont || kf->CC != 2 || L.cin % 16 != 0 || P.cin % 16 != 0) continue;
+        // the slot the projection reads must hold split cells when conv1 runs: it does if a 2xf16 layer reads it anyway
+        std::vector<float> mul, bias(L.cout, 0.f);
+        if (L.b_off >= 0) memcpy(bias.data(), blob + L.b_off, L.cout * sizeof(float));
+        if (L.post_scale_off >= 0) {
+            mul.assign(blob + L.post_scale_off, blob + L.post_scale_off + L.cout);
+            for (int c = 0; c < L.cout; ++c) bias[c] = bias[c] * mul[c] + blob[L.post_shift_off + c];
+        }
+        rt.f_n_cog = (L.cout + kf->MT - 1) / kf->MT;
+        rt.fold_cells = (int)split_cells(P.cin);
+        rt.f_n_chunks = (int)split_cells(L.cin) / kf->CC + rt.fold_cells / kf->CC;
+        std::vector<uint16_t> packed;
+        std::vector<float> inv;
+        pack_weights_split(*kf, blob + L.w_off, L.cout, L.cin, rt.f_n_cog, rt.f_n_chunks, packed, inv, blob + P.w_off, P.cin,
+                           mul.empty() ? nullptr : mul.data());
+        float* d = nullptr;
+        if (upload(ctx, m, reinterpret_cast<const float*>(packed.data()), (packed.size() + 1) / 2, &d)) return 1;
+        rt.d_wfold = d;
+        if (upload_chan(ctx, m, inv.data(), inv.size(), &rt.d_wscale_fold)) return 1;
+        if (upload_chan(ctx, m, bias.data(), bias.size(), &rt.d_bias_fold)) return 1;
+        rt.ks_fold = kf;
+        rt.fold_src = P.src;
+        pj.folded_into = i;
+        m->last_use[P.src] = std::max(m->last_use[P.src], i);       // conv1 now reads the projection's input itself
+    }
     m->split_ok = any_split;
     return 0;
 }
@@ -1027,19 +1107,21 @@ static void set_window(SplitArgs& a, const Rect& need, int scale = 1, int grow_x
 
 
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
+// (fold: the input of a folded 1x1 projection, split cells -- the layer then runs ks_fold with the projection's channels
+// appended to its K loop, no residual, eval-BN already inside weights and bias)
 static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot* sres, Slot& dst,
-                          const Slot* s2 = nullptr, bool pooled = false) {
+                          const Slot* s2 = nullptr, bool pooled = false, const Slot* fold = nullptr) {
     const tpz_layer& L = rt.L;
-    const SplitKernelInfo& ks = pooled ? *rt.ks_pool : *rt.ks;
+    const SplitKernelInfo& ks = fold ? *rt.ks_fold : pooled ? *rt.ks_pool : *rt.ks;
     SplitArgs a;
     memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const uint4*>(s1.p);
-    a.wpk = reinterpret_cast<const uint4*>(rt.d_wsplit);
-    a.wscale = rt.d_wscale;
-    a.bias = rt.d_bias;
+    a.wpk = reinterpret_cast<const uint4*>(fold ? rt.d_wfold : rt.d_wsplit);
+    a.wscale = fold ? rt.d_wscale_fold : rt.d_wscale;
+    a.bias = fold ? rt.d_bias_fold : rt.d_bias;
     a.res = sres ? reinterpret_cast<const uint4*>(sres->p) : nullptr;
-    a.post_scale = rt.d_post_scale;
-    a.post_shift = rt.d_post_shift;
+    a.post_scale = fold ? nullptr : rt.d_post_scale;
+    a.post_shift = fold ? nullptr : rt.d_post_shift;
     a.head_w = rt.d_head_w;
     a.head_b = rt.head_b;
     if (L.head) a.head_out = dst.p;
@@ -1075,7 +1157,20 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     if (L.dims == 3) {
         a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = 1; a.ooz = 0;
     }
-    const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * a.Hout * a.Wout;
+    double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * a.Hout * a.Wout;
+    if (fold) {
+        // out(y, x) += proj(h)(y + res_crop, x + res_crop); the centre tap of output y sits at tile-input row y - pad + (k/2) dil
+        a.in2 = reinterpret_cast<const uint4*>(fold->p);
+        a.fold_cells = rt.fold_cells;
+        a.cells_in = a.cells_in1 + rt.fold_cells;
+        a.fold_tap = (L.k * L.k) / 2;
+        a.in2_H = fold->H; a.in2_W = fold->W;
+        a.in2_oy = a.in2_ox = L.res_crop + L.pad - (L.k / 2) * L.dil;
+        a.n_chunks = rt.f_n_chunks;
+        flops += 2.0 * L.cout * (8.0 * rt.fold_cells) * (double)a.Hout * a.Wout;
+        set_window(a, dst.need);
+        return launch_split(ctx, ks, a, rt.f_n_cog, flops);
+    }
     set_window(a, dst.need);           // (a pooled dst keeps its need in the coordinates of the un-pooled conv output)
     return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
@@ -1452,7 +1547,7 @@ static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const 
     for (int i = 0; i < nl; ++i) {
         const LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        if (L.dims != 2) return need;
+        if (L.dims != 2 || rt.folded_into >= 0) return need;
         if (L.op == TPZ_OP_CONV) {
             const bool windowed = rt.ks || rt.ks_last || (rt.ks_stem && L.src == 0) || (rt.sphase.valid && !rt.sphase.ki_skip_stem);
             if (!windowed) return need;
@@ -1530,9 +1625,12 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
         const Slot& s1 = slots[L.src];
         if (!s1.set) { rc = fail(ctx, "layer %d reads unset slot %d", i, L.src); break; }
         Slot& dst = slots[L.dst];
-        if (L.op == TPZ_OP_CONV) {
+        if (L.op == TPZ_OP_CONV && split && rt.folded_into >= 0 && m->layers[rt.folded_into].ks_fold) {
+            // a 1x1 projection folded into the conv that adds it (prepare_split): nothing to run, its slot stays unset
+        } else if (L.op == TPZ_OP_CONV) {
+            const bool fold_here = split && rt.ks_fold && rt.fold_src >= 0 && slots[rt.fold_src].set;
             const Slot* s2 = L.src2 >= 0 ? &slots[L.src2] : nullptr;
-            const Slot* sres = L.res >= 0 ? &slots[L.res] : nullptr;
+            const Slot* sres = (L.res >= 0 && !fold_here) ? &slots[L.res] : nullptr;
             if ((s2 && !s2->set) || (sres && !sres->set)) { rc = fail(ctx, "layer %d reads an unset slot", i); break; }
             const Slot& geo = s2 ? *s2 : s1;
             if (s1.C + (s2 ? s2->C : 0) != L.cin) {
@@ -1551,7 +1649,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             // which kernels run the layer: the 2xf16 per-parity twin, a 2xf16 kernel, or the fp32 path
             const bool exact2x = s2 && s2->H == 2 * s1.H && s2->W == 2 * s1.W && (L.dims == 2 || s2->D == 2 * s1.D);
             const bool use_sphase = split && rt.sphase.valid && exact2x;
-            const bool use_split = split && rt.ks && !use_sphase;
+            const bool use_split = split && rt.ks && !use_sphase;      // (fold_here implies it)
             const bool use_stem = split && rt.ks_stem && !s1.split;
             const bool use_last = split && rt.ks_last;
             const bool stem_split = split && !use_sphase && !use_split && !use_stem && rt.ki_stem_split;
@@ -1584,6 +1682,13 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             if (use_stem) rc = run_stem_split(ctx, rt, v1, dst, fuse_pool);
             else if (use_last) rc = run_last_split(ctx, rt, v1, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
             else if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
+            else if (use_split && fold_here) {
+                Slot vf = slots[rt.fold_src];
+                vf.p = slot_as(ctx, slots[rt.fold_src], true);
+                vf.split = true;
+                if (!vf.p) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
+                rc = run_conv_split(ctx, rt, v1, nullptr, dst, nullptr, false, &vf);
+            }
             else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr, fuse_pool);
             else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
                                (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
