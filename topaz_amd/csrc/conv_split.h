@@ -478,7 +478,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             if (!(ABL & 2) && sub == 0) {
                 // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
                 // start their MFMAs at once and keep the matrix core busy meanwhile)
-                const bool iss = a.issuer_half && C::WAVES == 8 && !a.in2;
+                // (not with a second source whose offset table is rewritten mid-loop by each thread for itself -- except the
+                // folded projection, which pays one extra barrier at the switch instead)
+                const bool iss = a.issuer_half && C::WAVES == 8 && (!a.in2 || folded);
                 const int reps = iss ? (wave >= 4 ? 2 : 0) : 1;
                 if constexpr (!(ABL & 128)) {
                     for (int rep = 0; rep < reps; ++rep) {
@@ -488,7 +490,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     }
                 }
                 if (!(ABL & 256) && pf < a.n_chunks && r0 < C::NR) {
-                    if (r0 == 0 && pf == chunks1) compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win);         // switching to the second source
+                    if (r0 == 0 && pf == chunks1) {
+                        compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win);         // switching to the second source
+                        if (iss) __syncthreads();                                     // the issuing waves read other threads' entries
+                    }
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
 #pragma unroll 1
