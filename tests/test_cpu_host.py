@@ -183,6 +183,40 @@ def test_unpickler_allowlist_refuses_foreign_globals(tmp_path):
     assert arch == 'conv127'
 
 
+def test_unpickler_nested_payload_stays_inside_the_allowlist(tmp_path):
+    """torch.storage._load_from_bytes is `torch.load(BytesIO(b), weights_only=False)` with the STANDARD unpickler: a model
+    file could wrap any payload in it.  The name is mapped onto a wrapper that re-enters this module's own
+    unpickler: the nested os.system is refused, a nested tensor still loads."""
+    import io
+    import os
+    import pickle
+    import torch
+    from topaz_amd.model.unpickle import _PickleModule
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('echo pwned > ' + str(tmp_path / 'pwned2'),))
+
+    class Nested:
+        def __init__(self, payload):
+            buf = io.BytesIO()
+            torch.save(payload, buf)
+            self.b = buf.getvalue()
+
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (self.b,))
+
+    bad = tmp_path / 'nested_evil.sav'
+    torch.save({'x': Nested(Evil())}, str(bad), pickle_protocol=4)
+    with pytest.raises(pickle.UnpicklingError, match='system'):
+        torch.load(str(bad), map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    assert not (tmp_path / 'pwned2').exists()
+    ok = tmp_path / 'nested_ok.sav'
+    torch.save({'x': Nested(torch.arange(5.))}, str(ok), pickle_protocol=4)
+    got = torch.load(str(ok), map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    assert torch.equal(got['x'], torch.arange(5.))
+
+
 def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
     """UDenoiseNet3 (--arch unet3) has UDenoiseNet's parameter names but returns x - dec1(h): it must be refused, not
     evaluated as a UDenoiseNet.  The classes are faked under the reference's module path for pickling."""

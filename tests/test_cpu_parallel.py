@@ -107,6 +107,48 @@ def test_launch_local_ranks_propagates_failure():
     assert launch_local_ranks(2, [sys.executable, '-c', code]) == 3        # rank 0 is terminated, not waited for
     assert time.time() - t0 < 30
     assert launch_local_ranks(2, [sys.executable, '-c', 'import os; assert "RANK" in os.environ']) == 0
+    # ranks are started without a stdin to fight over
+    assert launch_local_ranks(2, [sys.executable, '-c', 'import sys; sys.exit(0 if sys.stdin.read() == "" else 5)']) == 0
+
+
+def test_launcher_reads_stdin_once_for_all_ranks(monkeypatch):
+    """`topaz extract --gpus N` with the micrograph list on stdin: the launcher reads stdin ONCE and hands
+    every rank the whole list through an @file argument; rank processes get no stdin.  (N ranks sharing one pipe would each
+    read a part of it, take that part for the whole list and shard it again: most micrographs silently never processed.)"""
+    import io
+    import sys
+    from topaz_amd import main as tmain
+    from topaz_amd import parallel
+    seen = {}
+
+    def fake_launch(n, cmd, **kw):
+        seen['n'] = n
+        seen['cmd'] = list(cmd)
+        lists = [a for a in cmd if a.startswith('@')]
+        assert len(lists) == 1
+        seen['names'] = open(lists[0][1:]).read().split()
+        return 0
+
+    monkeypatch.setattr(parallel, 'launch_local_ranks', fake_launch)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    names = [f'/data/mic_{i:03d}.mrc' for i in range(37)]
+    monkeypatch.setattr(sys, 'stdin', io.StringIO('\n'.join(names) + '\n\n'))
+    assert tmain.main(['extract', '-m', 'resnet8_u32', '-r', '8', '--gpus', '4']) == 0
+    assert seen['n'] == 4 and seen['names'] == names
+    import os
+    assert not os.path.exists([a for a in seen['cmd'] if a.startswith('@')][0][1:])      # the list file is removed afterwards
+    # a rank parses the same command line: the @file expands to the positional paths
+    from topaz_amd.commands import extract as cext
+    import argparse
+    p = argparse.ArgumentParser(fromfile_prefix_chars='@')
+    cext.add_arguments(p)
+    lf = os.path.join(os.path.dirname(__file__), '_tmp_list.txt')
+    open(lf, 'w').write('\n'.join(names) + '\n')
+    try:
+        a = p.parse_args(['-m', 'resnet8_u32', '-r', '8', '--gpus', '4', '@' + lf])
+    finally:
+        os.unlink(lf)
+    assert a.paths == names
 
 
 def _sum_worker(rank, world, port, q):

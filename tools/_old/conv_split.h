@@ -38,7 +38,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <vector>
 
 #include "conv_mfma.h"
 #include "split_fmt.h"
@@ -99,30 +98,6 @@ struct SplitArgs {
     // (13 GB per micrograph).  In the slot stream each folded chunk (CC = 2 cells) is one step: slots (centre tap, cell 0 / 1)
     // and (next tap, cell 0 / 1), the latter with zero weights.  Kernels with one step per stage only (SPS == 1).
     int fold_cells, fold_tap, in2_H, in2_W, in2_oy, in2_ox;
-    // the tile-invariant schedule of the K loop (split_make_plan, built once per layer on the host): entry 0 describes the
-    // fetch of chunk 0 in the prologue, entry 1 + s step s -- where its B fragments lie in the LDS and which share of which
-    // chunk's input tile it prefetches.  The kernel reads one entry per step through the scalar cache.
-    const struct SplitStep* plan;
-};
-
-// One step of a tile's K loop as the kernel sees it (32 bytes = one s_load_dwordx8).  Everything that depends only on the
-// layer (cells, taps, sources, stages) and not on the tile is decided here, on the host: the kernel's own per-step scalar
-// code is a handful of instructions (round 2: ~350 instructions with 25 branches per step on the 128-channel tiles,
-// executed by all eight waves before their first MFMA of the step).
-struct SplitStep {
-    uint16_t bofs[4];         // LDS byte offset / 16 of the step's B fragments for lane group kb: input buffer + slot (tap, cell)
-    uint32_t dma;             // input DMA issued at this step (SPLIT_DMA_*)
-    uint32_t cidx;            // 2-D: index of the fetched chunk within its source tensor
-    uint32_t cell[4];         // plane-stacked 3-D: per cell of the fetched chunk  bit 0 valid, bit 1 from `in2`,
-                              // bits 2-7 kz, bits 8.. cell index within its source
-};
-enum : uint32_t {
-    SPLIT_DMA_ROUNDS = 0xffu,         // bit r: DMA round r of the chunk's tile is issued at this step
-    SPLIT_DMA_BUF = 1u << 8,          // destination input buffer
-    SPLIT_DMA_NCELL_SHIFT = 9,        // bits 9-11: the chunk's cells that exist when fewer than CC (0 = all CC)
-    SPLIT_DMA_SWITCH = 1u << 12,      // first fetch from the second source: its offset table replaces the first one's
-    SPLIT_DMA_SRC2 = 1u << 13,        // 2-D: the chunk comes from `in2`
-    SPLIT_DMA_ANY = 1u << 31,
 };
 
 struct SplitSlot {
@@ -137,9 +112,7 @@ struct SplitCfg {
     // 8 waves: one workgroup per CU (the big dilated tiles need most of the LDS); 4 waves: two per CU, so that
     // one workgroup's prologue / epilogue / barrier waits overlap the other's MFMAs (small-halo, short-K layers)
     static constexpr int WAVES = WAVES_, THREADS = 64 * WAVES_, WGS_PER_CU = WAVES_ == 8 ? 1 : 2;
-    static constexpr bool UNIFORM_DMA = (MT_ >= 128 && WAVES_ == 8);    // how the LDS-DMA is issued (see fetch)
-    // the upper half of an 8-wave workgroup may issue the whole step's DMA (SplitArgs::issuer_half): -3 .. -4 % on the wide tiles
-    static constexpr bool ISSUER_HALF = (MT_ >= 96 && WAVES_ == 8);
+    static constexpr bool UNIFORM_DMA = (MT_ >= 128 && WAVES_ == 8);    // how the LDS-DMA is issued (see issue_input)
     static constexpr int MW = MT / 16;
     static constexpr int RPW = TH / WAVES;
     static constexpr int NFC = TW / 16;
@@ -199,8 +172,9 @@ struct SplitCfg {
     static constexpr int WR = (W_STAGE_BYTES + THREADS * 16 - 1) / (THREADS * 16);  // DMA rounds per weight stage
     static constexpr int OFF_W = 2 * IN_BUF;
     static constexpr int OFF_TAB = OFF_W + 2 * W_STAGE_BYTES;
-    static constexpr int LDS_BYTES = OFF_TAB + (NPC * 4 + 15) / 16 * 16;
-    static_assert(NR <= 8, "the plan carries the DMA rounds of a step as a byte mask");
+    static constexpr int OFF_SLOT = OFF_TAB + NPC * 4;
+    static constexpr int N_SLOT_TAB = CONT ? Q : NSTEP * 4;
+    static constexpr int LDS_BYTES = OFF_SLOT + (N_SLOT_TAB + 3) / 4 * 16;
     static_assert(TH % WAVES == 0 && TW % 16 == 0 && MT % 16 == 0, "tile shape");
     static_assert(PLANE_BYTES + (RPW * ITW + TW) * 16 < 65536, "ds_read immediates are 16 bit");
     static_assert(LDS_BYTES <= 160 * 1024 / WGS_PER_CU, "LDS per workgroup");
@@ -208,103 +182,6 @@ struct SplitCfg {
     // every chunk's prefetch window (~ Q / 4 - 1 steps) must contain at least one whole, aligned stage
     static_assert(SPS == 1 || (CONT && Q >= 8 * SPS), "multi-step stages: continuous slot stream, chunks of >= 2 * SPS steps");
 };
-
-// What a plan depends on (besides the kernel configuration): the K loop's cells and sources, nothing of the tile or image size
-struct SplitPlanKey {
-    int cells_in, cells_in1, n_chunks, has_in2, vol, KZ, fold_cells, fold_tap;
-};
-
-// Host: the schedule of one tile's K loop (SplitStep) for configuration C.  Entry 0 = the fetch of chunk 0 (all rounds, issued
-// in the prologue), entry 1 + s = step s.  Mirrors pack_weights_split (runtime.hip), which lays the weights out in the same
-// (step, lane group) -> (chunk, tap, cell) order.
-template <class C>
-void split_make_plan(const SplitPlanKey& k, std::vector<SplitStep>& out) {
-    const bool vol = k.vol != 0;
-    const bool folded = C::CONT && C::SPS == 1 && k.fold_cells > 0;
-    const int vcells = (folded ? k.cells_in1 : k.cells_in) * (vol ? k.KZ : 1);
-    const int n_full = vcells / C::CC, n_rem = vcells - n_full * C::CC;
-    const int n_stages_a = C::CONT ? C::cont_stages(vcells) : k.n_chunks * C::NSTEP;
-    const int n_stages = n_stages_a + (folded ? k.fold_cells / C::CC : 0);
-    const int chunks1 = (k.has_in2 && !vol) ? k.cells_in1 / C::CC : k.n_chunks;
-    auto cont_off = [](int q) {
-        const SplitSlot sl = C::cont_slot(q);
-        return (sl.c * C::CELL_STRIDE + sl.ky * C::ITW + sl.kx * C::D) * 16;
-    };
-    // the fetch of chunk `pf`, rounds `rmask`
-    auto fetch = [&](SplitStep& e, int pf, unsigned rmask, bool sw) {
-        e.dma = SPLIT_DMA_ANY | (rmask & SPLIT_DMA_ROUNDS) | ((pf & 1) ? SPLIT_DMA_BUF : 0u) | (sw ? SPLIT_DMA_SWITCH : 0u);
-        if (!vol) {
-            const bool second = pf >= chunks1;
-            if (second) e.dma |= SPLIT_DMA_SRC2;
-            e.cidx = (uint32_t)(second ? pf - chunks1 : pf);
-            const int have = k.cells_in - pf * C::CC;
-            if (have < C::CC) e.dma |= (uint32_t)(have > 1 ? have : 1) << SPLIT_DMA_NCELL_SHIFT;     // (a chunk that exists has >= 1 cell)
-        } else {
-            for (int j = 0; j < C::CC && j < 4; ++j) {
-                const int v = pf * C::CC + j, kz = v / k.cells_in, c = v - kz * k.cells_in;
-                if (kz >= k.KZ) { e.cell[j] = 0; continue; }
-                const bool l2 = c >= k.cells_in1;
-                e.cell[j] = 1u | (l2 ? 2u : 0u) | (uint32_t)kz << 2 | (uint32_t)(l2 ? c - k.cells_in1 : c) << 8;
-            }
-        }
-    };
-    out.assign((size_t)n_stages + 1, SplitStep{});
-    fetch(out[0], 0, (1u << C::NR) - 1, false);
-    for (int s = 0; s < n_stages; ++s) {
-        SplitStep& e = out[(size_t)s + 1];
-        for (int l4 = 0; l4 < 4; ++l4) {
-            int off;
-            if (C::CONT) {
-                if (folded && s >= n_stages_a) {
-                    off = ((chunks1 + s - n_stages_a) & 1) * C::IN_BUF + cont_off(k.fold_tap * C::CC + l4);
-                } else {
-                    int G = 4 * s + l4, cg = G / C::Q, q = G - cg * C::Q;
-                    if (cg >= n_full) {
-                        // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond it the
-                        // padding slots of the last step (zero weights, any valid address)
-                        const int q2 = G - n_full * C::Q;
-                        cg = n_full < k.n_chunks ? n_full : k.n_chunks - 1;
-                        q = (n_rem > 0 && q2 < C::TAPS * n_rem) ? (q2 / n_rem) * C::CC + (q2 % n_rem) : 0;
-                    }
-                    off = (cg & 1) * C::IN_BUF + cont_off(q);
-                }
-            } else {
-                const int ch = s / C::NSTEP;
-                off = (ch & 1) * C::IN_BUF + C::slot_lds_off(s - ch * C::NSTEP, l4);
-            }
-            e.bofs[l4] = (uint16_t)(off / 16);
-        }
-        // ---- prefetch: a share of the next chunk's tile (stages only issue at their first step)
-        const int stage = s / C::SPS;
-        if (s % C::SPS != 0) continue;
-        int pf, r0, rstride;
-        if (C::CONT) {
-            const int ch = (4 * s) / C::Q;
-            pf = ch + 1;
-            // buffer pf & 1 is free once the last slot of chunk pf - 2 is done and must be full before the first slot of chunk
-            // pf: steps [ws, we], i.e. the stages that lie wholly inside them; a stage that straddles two chunks issues nothing
-            const int ws = pf >= 2 ? (C::Q * (pf - 1) - 1) / 4 + 1 : 0;
-            const int we = (C::Q * pf) / 4 - 1;
-            const int gs = (ws + C::SPS - 1) / C::SPS, ge = (we + 1) / C::SPS - 1;
-            r0 = (stage >= gs && stage <= ge) ? stage - gs : C::NR;
-            rstride = ge - gs + 1;
-            if (folded && s >= n_stages_a) {        // a folded chunk lasts one step: the next one is fetched whole during it
-                pf = chunks1 + (s - n_stages_a) + 1;
-                r0 = 0;
-                rstride = 1;
-            }
-        } else {
-            const int ch = s / C::NSTEP;
-            pf = ch + 1;
-            r0 = s - ch * C::NSTEP;
-            rstride = C::NSTEP;
-        }
-        if (pf >= k.n_chunks || r0 >= C::NR) continue;
-        unsigned rmask = 0;
-        for (int r = r0; r < C::NR; r += rstride) rmask |= 1u << r;
-        fetch(e, pf, rmask, r0 == 0 && pf == chunks1);
-    }
-}
 
 // EPI: as conv_mfma.h (EPI_PLAIN / EPI_RES / EPI_RES_POST / EPI_HEAD) with split outputs (the head: fp32 scores);
 // EPI_PLAIN_F32 = plain epilogue storing fp32 planes, for a layer whose consumer is not on the 2xf16 path.
@@ -320,18 +197,12 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 //   16384 DMA issued but never waited for inside the K loop (what the latency of a stage's own prefetch costs)
 //   2048 clock probe: every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
 //        to the two 64-bit counters behind a.flag -> effective clock of the variant (DVFS: the chip runs at its power limit)
-// MODE: what the instantiation can do besides a plain single-source 2-D conv -- bit 0: a second source (`in2`: fused upsample +
-// concat, space-to-depth skip cell, folded projection), bit 1: plane-stacked 3-D.  The library launches MODE 0 whenever a layer
-// needs neither (every layer of the scoring networks but the folded ones, most of the U-Nets'): its per-step scalar code then
-// carries none of the other modes' selects and branches.
-template <class C, int EPI, int ABL = 0, int MODE = 3>
+template <class C, int EPI, int ABL = 0>
 __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
-    constexpr bool HAS2 = (MODE & 1) != 0, VOLM = (MODE & 2) != 0;
-    const uint4* const in2 = HAS2 ? a.in2 : nullptr;
-    const int fold_cells = HAS2 ? a.fold_cells : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned* lds_tab = reinterpret_cast<unsigned*>(lds + C::OFF_TAB);
+    unsigned* lds_slot = reinterpret_cast<unsigned*>(lds + C::OFF_SLOT);
 
     const int tid = threadIdx.x;
     unsigned long long probe_c0 = 0, probe_r0 = 0;
@@ -366,15 +237,23 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         pad_z = (a.phase_k / 2 - ooz + 1) / 2;
     }
     const int ybase = y0 - pad_y, xbase = x0 - pad_x;
-    const bool vol = VOLM && (a.KZ > 1 || a.Din > 1);        // plane-stacked 3-D addressing
+    const bool vol = a.KZ > 1 || a.Din > 1;                  // plane-stacked 3-D addressing
 
     constexpr unsigned OOB = 0xffffffffu;
-    // ---- the chunk-invariant global byte offset of every LDS cell of a source
+    // ---- tables: slot offsets, and the chunk-invariant global byte offset of every LDS cell of a source
+    if constexpr (C::CONT) {
+        if (tid < C::Q) {
+            const SplitSlot sl = C::cont_slot(tid);
+            lds_slot[tid] = (unsigned)((sl.c * C::CELL_STRIDE + sl.ky * C::ITW + sl.kx * D) * 16);
+        }
+    } else {
+        if (tid < C::NSTEP * 4) lds_slot[tid] = (unsigned)C::slot_lds_off(tid >> 2, tid & 3);
+    }
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
     // (tid and the sizes nearest_src() divides are passed in: the co-group loop hands over opaque copies, so that nothing of this prologue is
     // hoisted out of that loop and kept in registers across the K loop)
     auto compute_offsets = [&](bool second, int tid, int H1, int W1, int Hup, int Wup) {
-        const bool fold2 = second && fold_cells > 0;       // the folded source has its own size and origin
+        const bool fold2 = second && a.fold_cells > 0;       // the folded source has its own size and origin
         const int Hs = fold2 ? a.in2_H : second ? a.Hin : H1, Ws = fold2 ? a.in2_W : second ? a.Win : W1;
         const int Hv = fold2 ? a.in2_H : a.Hin, Wv = fold2 ? a.in2_W : a.Win;
 #pragma unroll 1
@@ -389,22 +268,21 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 if ((unsigned)gy < (unsigned)Hv && (unsigned)gx < (unsigned)Wv) {
                     int sy = gy, sx = gx;
                     if (!second && ups) { sy = nearest_src(gy, H1, Hup); sx = nearest_src(gx, W1, Wup); }
-                    // 3-D: the in-plane part only; the (cell, plane) part is added per chunk in fetch
+                    // 3-D: the in-plane part only; the (cell, plane) part is added per chunk in issue_input
                     off = vol ? (unsigned)(((size_t)sy * Ws + sx) * 16) : (unsigned)((((size_t)c * Hs + sy) * Ws + sx) * 16);
                 }
                 lds_tab[g] = off;              // read back by the same thread only
             }
         }
     };
+    // chunks [0, chunks1) read `in`, the rest `in2` (the host guarantees cells_in1 % CC == 0 with a second source)
+    // (plane-stacked 3-D: the source is chosen per cell in issue_input, chunks never switch)
+    const int chunks1 = (a.in2 && !vol) ? a.cells_in1 / C::CC : a.n_chunks;
     const size_t plane1 = (size_t)a.cells_in1 * a.H1 * a.W1 * (vol ? a.Din : 1);   // cells per plane of `in`
-    const size_t hw2 = fold_cells > 0 ? (size_t)a.in2_H * a.in2_W : (size_t)a.Hin * a.Win;      // one cell plane of `in2`
+    const size_t hw2 = a.fold_cells > 0 ? (size_t)a.in2_H * a.in2_W : (size_t)a.Hin * a.Win;      // one cell plane of `in2`
     const size_t plane2 = (size_t)(a.cells_in - a.cells_in1) * hw2 * (vol ? a.Din : 1);           // ... of `in2`
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)lds;
     const void* zsrc = uniform_ptr(a.zeros);
-    // the plan is read through the scalar cache: one s_load_dwordx8 per step, a step ahead of its use
-    typedef uint32_t StepW __attribute__((ext_vector_type(8)));
-    typedef const __attribute__((address_space(4))) StepW* plan_ptr_t;
-    const plan_ptr_t plan = (plan_ptr_t)a.plan;
 
     // One LDS-DMA instruction moves 16 bytes per lane, 1 KiB per wave.  Two ways to issue it:
     //  * per-lane 64-bit source address through the builtin (glds16): lanes whose cell lies outside the image (or past the last
@@ -418,77 +296,61 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
                                          (__attribute__((address_space(3))) void*)(size_t)lds_addr, 16, 0, 0);
     };
-    // The rounds `rounds` (bit r) of the input tile of the chunk that plan entry P describes -> its input buffer (both planes);
-    // (tid, wave): whose share.  Everything but the table lookup and the DMA itself is scalar.
-    auto fetch = [&](const StepW& P, unsigned rounds, int tid, int wave) {
-        const unsigned d = P[2];
-        const int buf = (d & SPLIT_DMA_BUF) ? 1 : 0;
-        const bool second = HAS2 && (d & SPLIT_DMA_SRC2) != 0;
-        const unsigned ncell = (d >> SPLIT_DMA_NCELL_SHIFT) & 7u;       // 0: every cell of the chunk exists
-        const uint4* chunk = second ? in2 + (size_t)P[3] * (C::CC * hw2) : a.in + (size_t)P[3] * (C::CC * (size_t)a.H1 * a.W1);
-        const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
-        const size_t lo_delta0 = (second ? plane2 : plane1) * 16;       // bytes from a hi cell to its lo cell
-        // plane-stacked 3-D: virtual cell v = kz * cells + c of the chunk is cell c of input plane oz + kz - pad_z, of `in` or
-        // `in2` (32-bit byte offsets from the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
-        constexpr int CCV = C::CC < 4 ? C::CC : 4;
-        unsigned coff[CCV], cflag[CCV];
-        if (vol) {
-#pragma unroll
-            for (int j = 0; j < CCV; ++j) {
-                const unsigned cv = P[4 + j];
-                const int iz = oz + (int)((cv >> 2) & 63u) - pad_z;
-                const bool ok = (cv & 1u) && (unsigned)iz < (unsigned)a.Din;
-                coff[j] = (unsigned)((((size_t)(cv >> 8) * a.Din + iz) * a.Hin) * a.Win * 16);
-                cflag[j] = (ok ? 1u : 0u) | (HAS2 ? (cv & 2u) : 0u);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < C::NR; ++r) {
-            if (!((rounds >> r) & 1u)) continue;
-            const int g = r * C::THREADS + tid;
-            if ((r + 1) * C::THREADS <= C::NPC || g < C::NPC) {
-                unsigned off = lds_tab[g];
-                size_t lo_delta = lo_delta0;
-                bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
-                if (!vol) {
-                    if (ncell != 0 && g >= (int)ncell * C::CELL_STRIDE) off = OOB;      // cells past the last channel
-                } else {
-                    unsigned co = coff[0], cf = cflag[0];
-#pragma unroll
-                    for (int j = 1; j < CCV; ++j)
-                        if (g >= j * C::CELL_STRIDE) { co = coff[j]; cf = cflag[j]; }
-                    if (!(cf & 1u)) off = OOB;
-                    else if (off != OOB) { off += co; lane2 = HAS2 && (cf & 2u) != 0; }
+    // round r of the input tile of chunk ch -> input buffer buf (both planes)
+    auto issue_input = [&](int ch, int buf, int r, int tid, int wave) {
+        const int g = r * C::THREADS + tid;
+        if (g < C::NPC) {
+            const bool second = ch >= chunks1;
+            const uint4* chunk = second ? a.in2 + (size_t)(ch - chunks1) * C::CC * hw2
+                                        : a.in + (size_t)ch * C::CC * a.H1 * a.W1;
+            if constexpr ((ABL & 8192) != 0) chunk = a.in;            // (ABL 8192: every tile reads one L2-resident window)
+            const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
+            size_t lo_delta = ((ABL & 8192) ? (size_t)0x20000 : second ? plane2 : plane1) * 16;      // bytes from a hi cell to its lo cell
+            unsigned off = (ABL & 4096) ? (unsigned)g * 16u : lds_tab[g];      // (ABL 4096: no table, contiguous source)
+            if constexpr ((ABL & 8192) != 0) off = off == OOB ? off : (off & 0x1ffff0u);
+            bool lane2 = false;                  // 3-D: this lane's cell comes from `in2`
+            if (!vol) {
+                if (ch * C::CC + g / C::CELL_STRIDE >= a.cells_in) off = OOB;    // cells past the last channel
+            } else {
+                // virtual cell v = kz * cells + c: cell c of input plane oz + kz - pad_z (32-bit byte offsets from
+                // the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
+                const int v = ch * C::CC + g / C::CELL_STRIDE;
+                const int kz = v / a.cells_in, c = v - kz * a.cells_in;
+                const int iz = oz + kz - pad_z;
+                if (kz >= a.KZ || (unsigned)iz >= (unsigned)a.Din) off = OOB;
+                else if (off != OOB) {
+                    lane2 = c >= a.cells_in1;
+                    off += (unsigned)((((size_t)(lane2 ? c - a.cells_in1 : c) * a.Din + iz) * a.Hin) * a.Win * 16);
                 }
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
-                if constexpr (C::UNIFORM_DMA) {
-                    const void* blo = bhi + lo_delta;
-                    if (!__any(off == OOB || lane2)) {
+            }
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
+            if constexpr (C::UNIFORM_DMA) {
+                const void* blo = bhi + lo_delta;
+                if (!__any(off == OOB || lane2)) {
+                    glds_b128(off, bhi, dst);
+                    glds_b128(off, blo, dst + C::PLANE_BYTES);
+                } else {
+                    if (off == OOB) {
+                        glds_b128(0u, zsrc, dst);
+                        glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
+                    } else if (lane2) {
+                        const void* b2 = uniform_ptr(a.in2);
+                        const void* b2lo = uniform_ptr(a.in2 + plane2);
+                        glds_b128(off, b2, dst);
+                        glds_b128(off, b2lo, dst + C::PLANE_BYTES);
+                    } else {
                         glds_b128(off, bhi, dst);
                         glds_b128(off, blo, dst + C::PLANE_BYTES);
-                    } else {
-                        if (off == OOB) {
-                            glds_b128(0u, zsrc, dst);
-                            glds_b128(0u, zsrc, dst + C::PLANE_BYTES);
-                        } else if (lane2) {
-                            const void* b2 = uniform_ptr(in2);
-                            const void* b2lo = uniform_ptr(in2 + plane2);
-                            glds_b128(off, b2, dst);
-                            glds_b128(off, b2lo, dst + C::PLANE_BYTES);
-                        } else {
-                            glds_b128(off, bhi, dst);
-                            glds_b128(off, blo, dst + C::PLANE_BYTES);
-                        }
                     }
-                } else {
-                    const unsigned char* src = bhi;
-                    if (lane2) { src = reinterpret_cast<const unsigned char*>(in2); lo_delta = plane2 * 16; }
-                    const bool oob = off == OOB;
-                    const unsigned char* shi = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off;
-                    const unsigned char* slo = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off + lo_delta;
-                    glds16(shi, dst);
-                    glds16(slo, dst + C::PLANE_BYTES);
                 }
+            } else {
+                const unsigned char* src = bhi;
+                if (lane2) { src = reinterpret_cast<const unsigned char*>(a.in2); lo_delta = plane2 * 16; }
+                const bool oob = off == OOB;
+                const unsigned char* shi = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off;
+                const unsigned char* slo = oob ? reinterpret_cast<const unsigned char*>(zsrc) : src + off + lo_delta;
+                glds16(shi, dst);
+                glds16(slo, dst + C::PLANE_BYTES);
             }
         }
     };
@@ -507,21 +369,17 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     // per-lane LDS read bases (bytes)
     const unsigned b_lane = (unsigned)(((wave * C::RPW) * C::ITW + l15) * 16);
     const unsigned a_lane = (unsigned)(C::OFF_W + lane * 16);
-    // LDS address of this lane's B fragments of a step: its lane group's entry of the step's plan (buffer + tap + cell)
-    auto b_frag_base = [&](const StepW& P, int l4) -> const unsigned char* {
-        const unsigned w = (l4 & 2) ? P[1] : P[0];
-        return lds + b_lane + (((w >> ((l4 & 1) * 16)) & 0xffffu) << 4);
-    };
 
     float hsum[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) hsum[n] = 0.f;
     bool big = false;
 
-    const bool folded = C::CONT && C::SPS == 1 && fold_cells > 0;
+    const bool folded = C::CONT && C::SPS == 1 && a.fold_cells > 0;
     const int vcells = (folded ? a.cells_in1 : a.cells_in) * (vol ? a.KZ : 1);        // (virtual) cells of the K loop (all taps)
+    const int n_full = vcells / C::CC, n_rem = vcells - n_full * C::CC;      // full chunks; cells of a short last chunk
     const int n_stages_a = C::CONT ? C::cont_stages(vcells) : a.n_chunks * C::NSTEP;
-    const int n_stages = n_stages_a + (folded ? fold_cells / C::CC : 0);    // + one step per folded chunk
+    const int n_stages = n_stages_a + (folded ? a.fold_cells / C::CC : 0);    // + one step per folded chunk
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
     for (int cg = 0; cg < a.cog_inner; ++cg) {
@@ -535,21 +393,39 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        __syncthreads();                       // previous co-group done with the buffers
+        __syncthreads();                       // slot table written / previous co-group done with the buffers
         // the prologue of a co-group works from opaque copies of the thread id and the source size: its lane-dependent
         // values are then computed here and die here, instead of being hoisted out of this loop and spilled across the
         // K loop of the fused-head variant (which runs two co-groups per tile at 256 VGPRs)
         int tid_p = tid, H1_p = a.H1, W1_p = a.W1, Hup_p = a.Hin, Wup_p = a.Win;
         asm volatile("" : "+v"(tid_p), "+s"(H1_p), "+s"(W1_p), "+s"(Hup_p), "+s"(Wup_p));
         const int wave_p = __builtin_amdgcn_readfirstlane(tid_p >> 6), l4_p = (tid_p & 63) >> 4;
-        const StepW P0 = plan[0];              // the fetch of chunk 0
-        StepW P = plan[1];                     // step 0
-        compute_offsets((P0[2] & SPLIT_DMA_SRC2) != 0, tid_p, H1_p, W1_p, Hup_p, Wup_p);
-        fetch(P0, (1u << C::NR) - 1u, tid_p, wave_p);
+        compute_offsets(chunks1 == 0, tid_p, H1_p, W1_p, Hup_p, Wup_p);
+#pragma unroll 1
+        for (int r = 0; r < C::NR; ++r) issue_input(0, 0, r, tid_p, wave_p);
         issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid_p, wave_p);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // LDS address of this lane's B fragments of step st (its slot of the step: tap + cell of the chunk's tile)
+        auto b_frag_base = [&](int st, int l4) -> const unsigned char* {
+            if constexpr (C::CONT) {
+                if (folded && st >= n_stages_a)       // a folded chunk: the centre tap (and its zero-weight neighbour), cells 0 / 1
+                    return lds + ((chunks1 + st - n_stages_a) & 1) * C::IN_BUF + b_lane + lds_slot[a.fold_tap * C::CC + l4];
+                int G = 4 * st + l4, cg2 = G / C::Q, q = G - cg2 * C::Q;
+                if (cg2 >= n_full) {
+                    // the short last chunk (fewer than CC cells): slot = (tap, cell) over its own n_rem cells; beyond
+                    // it the padding slots of the last step (zero weights, any valid address)
+                    const int q2 = G - n_full * C::Q;
+                    cg2 = n_full < a.n_chunks ? n_full : a.n_chunks - 1;
+                    q = (n_rem > 0 && q2 < C::TAPS * n_rem) ? (q2 / n_rem) * C::CC + (q2 % n_rem) : 0;
+                }
+                return lds + (cg2 & 1) * C::IN_BUF + b_lane + lds_slot[q];
+            } else {
+                const int ch = st / C::NSTEP;
+                return lds + (ch & 1) * C::IN_BUF + b_lane + lds_slot[(st - ch * C::NSTEP) * 4 + l4];
+            }
+        };
         // The first fragments of a step -- all its B fragments (hi, lo) and A(0) -- are loop-carried registers: they are
         // refreshed IN PLACE for step s + 1 during the last channel fragment of step s, each right after the last MFMA
         // that reads its register has been issued (an MFMA reads its A/B operands at issue; the LDS data lands >= 64
@@ -557,7 +433,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         f16x8 bh[NW], bo[NW], ah[2], ao[2];
         auto b_off = [&](int n) { return ((n / NFC) * C::ITW + (n % NFC) * 16) * 16; };
         {
-            const unsigned char* bl = b_frag_base(P, l4_p);
+            const unsigned char* bl = b_frag_base(0, l4_p);
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 bh[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n));
@@ -572,15 +448,39 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         for (int s = 0; s < n_stages; ++s) {
             const int stage = s / C::SPS, sub = s - stage * C::SPS;      // (SPS = 1: stage = s, sub = 0)
             const bool stage_end = sub == C::SPS - 1 || s == n_stages - 1;
-            // the next step's plan entry: requested now, first used behind this step's barrier
-            const StepW Pn = plan[1 + (s + 1 < n_stages ? s + 1 : s)];
-            // ---- prefetch by DMA: the weights of the next stage, a share of the next chunk's input tile
+            // chunk of the stage's first slot; pf = chunk whose tile is being prefetched, r0 / rstride = its DMA rounds
+            int ch, pf, r0, rstride;
+            if constexpr (C::CONT) {
+                ch = (4 * s) / C::Q;
+                pf = ch + 1;
+                // buffer pf & 1 is free once the last slot of chunk pf - 2 is done and must be full before the first
+                // slot of chunk pf: steps [ws, we], i.e. the stages that lie wholly inside them; a stage that straddles
+                // two chunks issues nothing
+                const int ws = pf >= 2 ? (C::Q * (pf - 1) - 1) / 4 + 1 : 0;
+                const int we = (C::Q * pf) / 4 - 1;
+                const int gs = (ws + C::SPS - 1) / C::SPS, ge = (we + 1) / C::SPS - 1;
+                r0 = (stage >= gs && stage <= ge) ? stage - gs : C::NR;
+                rstride = ge - gs + 1;
+                if (folded && s >= n_stages_a) {
+                    // a folded chunk lasts one step: the next one is fetched whole during this step
+                    ch = chunks1 + (s - n_stages_a);
+                    pf = ch + 1;
+                    r0 = 0;
+                    rstride = 1;
+                }
+            } else {
+                ch = s / C::NSTEP;
+                pf = ch + 1;
+                r0 = s - ch * C::NSTEP;
+                rstride = C::NSTEP;
+            }
+            // ---- prefetch by DMA: the weights of the next step, a share of the next chunk's input tile
             if (!(ABL & 2) && sub == 0) {
                 // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
                 // start their MFMAs at once and keep the matrix core busy meanwhile)
                 // (not with a second source whose offset table is rewritten mid-loop by each thread for itself -- except the
                 // folded projection, which pays one extra barrier at the switch instead)
-                const bool iss = C::ISSUER_HALF && a.issuer_half && (!in2 || folded);
+                const bool iss = a.issuer_half && C::WAVES == 8 && (!a.in2 || folded);
                 const int reps = iss ? (wave >= 4 ? 2 : 0) : 1;
                 if constexpr (!(ABL & 128)) {
                     for (int rep = 0; rep < reps; ++rep) {
@@ -589,14 +489,17 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         if (left > 0) issue_weights(wcog, stage + 1, (left < C::SPS ? left : C::SPS) * C::W_STEP_BYTES, (stage + 1) & 1, vt, vw);
                     }
                 }
-                if (!(ABL & 256) && (P[2] & SPLIT_DMA_ANY)) {
-                    if (HAS2 && (P[2] & SPLIT_DMA_SWITCH)) {
+                if (!(ABL & 256) && pf < a.n_chunks && r0 < C::NR) {
+                    if (r0 == 0 && pf == chunks1) {
                         compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win);         // switching to the second source
                         if (iss) __syncthreads();                                     // the issuing waves read other threads' entries
                     }
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
-                        fetch(P, P[2] & SPLIT_DMA_ROUNDS, vt, vw);
+#pragma unroll 1
+                        for (int r = r0; r < C::NR; r += rstride) {
+                            issue_input(pf, pf & 1, r, vt, vw);
+                        }
                     }
                 }
             }
@@ -606,10 +509,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             //   B fragments and A(0) of step s + 1.  The matrix core is not left idle for an LDS round trip after every
             //   barrier (150 - 250 cycles of a step of 768 (MT = 64) ... 3072 (MT = 128, 8 waves) cycles).
             //   MFMA order within a channel fragment: ah*bo, ah*bh, ao*bh -- the lo halves of B are released first.
+            const unsigned char* bl_next = b_frag_base(s + 1 < n_stages ? s + 1 : s, l4);      // (slot-table lookup: early)
             const unsigned char* al = lds + a_lane + (stage & 1) * C::W_STAGE_BYTES + sub * C::W_STEP_BYTES;
             const int stage_n = (s + 1) / C::SPS;
             const unsigned char* al_next = lds + a_lane + (stage_n & 1) * C::W_STAGE_BYTES + (s + 1 - stage_n * C::SPS) * C::W_STEP_BYTES;
-            const unsigned char* bl_next = nullptr;
             constexpr bool A0_EARLY = (MW % 2 == 0);          // slot 0 of ah / ao is free during the last fragment (slot 1)
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
@@ -627,6 +530,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     // sinks every fragment read to just before its first use and waits lgkmcnt(0) on it: 2 * MW exposed
                     // LDS latencies per step)
                     if constexpr (!(ABL & 16) && !(ABL & 8)) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // (the slot-table lookup)
 #pragma unroll
                         for (int mm = 0; mm + 1 < MW; ++mm) {
                             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // A(mm + 1)
@@ -639,7 +543,6 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this stage has landed
                         if constexpr (!(ABL & 4)) __syncthreads();
                     }
-                    bl_next = b_frag_base(Pn, l4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const bool last = m + 1 == MW;
@@ -687,7 +590,6 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            P = Pn;
         }
 
         // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store.

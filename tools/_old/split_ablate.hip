@@ -9,30 +9,16 @@ using namespace tpz;
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-// the K-loop schedule the kernel reads (conv_split.h split_make_plan), as the library builds it
-template <class C>
-const SplitStep* make_plan(const SplitArgs& a) {
-    SplitPlanKey k{};
-    k.cells_in = a.cells_in; k.cells_in1 = a.cells_in1; k.n_chunks = a.n_chunks; k.has_in2 = a.in2 != nullptr;
-    k.vol = 0; k.KZ = 1; k.fold_cells = a.fold_cells; k.fold_tap = a.fold_tap;
-    std::vector<SplitStep> h;
-    split_make_plan<C>(k, h);
-    SplitStep* d = nullptr;
-    if (hipMalloc(&d, h.size() * sizeof(SplitStep)) != hipSuccess) return nullptr;
-    (void)hipMemcpy(d, h.data(), h.size() * sizeof(SplitStep), hipMemcpyHostToDevice);
-    return d;
-}
-
 template <class C, int EPI, int ABL>
 float run(const SplitArgs& a, dim3 grid, int iters) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, ABL, 0>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, ABL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -74,7 +60,6 @@ int bench(const char* name, int cin, int cout, int H) {
     a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;
     a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
-    a.plan = make_plan<C>(a);
     dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
@@ -110,6 +95,9 @@ int bench(const char* name, int cin, int cout, int H) {
     RUN(2, "no per-step DMA issue");
     RUN(128, "no per-step WEIGHT DMA (input DMA kept)");
     RUN(256, "no per-step INPUT DMA (weight DMA kept)");
+    RUN(4096, "input DMA from contiguous addresses, no offset table");
+    RUN(8192, "input DMA from an L2-resident 2 MB window");
+    RUN(8192 | 4096, "input DMA contiguous + L2-resident");
     RUN(16384, "DMA issued, its arrival never waited for");
     RUN(16384 | 4, "DMA never waited for, no barrier");
     RUN(4, "no per-step barrier");
@@ -154,7 +142,6 @@ int quick(const char* name, int cin, int cout, int H) {
     a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;
     a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
-    a.plan = make_plan<C>(a);
     dim3 grid(a.tiles_x, a.tiles_y, n_cog / a.cog_inner);
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,

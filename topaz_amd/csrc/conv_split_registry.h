@@ -15,22 +15,29 @@ struct SplitKernelInfo {
     // steps of one tile's K loop over `cells` (virtual) cells
     int stages(int cells) const { return cont ? ((Q / CC) * cells + 3) / 4 : (cells + CC - 1) / CC * NSTEP; }
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
+    void (*make_plan)(const SplitPlanKey&, std::vector<SplitStep>&);     // the K-loop schedule the kernel reads (SplitArgs::plan)
     char name[160];
 };
 
 void register_split(const SplitKernelInfo& info);
 const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
+// two instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code) and the general one
+// (second source and / or plane-stacked 3-D)
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_split_kernel<C, EPI>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    if (!a.in2 && a.KZ <= 1 && a.Din <= 1) hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     return hipGetLastError();
 }
 
@@ -51,6 +58,7 @@ struct SplitRegistrar {
         i.cont = C::CONT ? 1 : 0; i.Q = C::Q;
         i.cont_slot = &split_cont_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
+        i.make_plan = &split_make_plan<C>;
         if (C::SPS == 1)
             snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,
                      i.D, i.MT, i.TH, i.TW, i.CC, i.WAVES, i.epi);

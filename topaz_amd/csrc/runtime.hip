@@ -117,6 +117,9 @@ struct tpz_ctx {
     unsigned* d_flag = nullptr;   // f16-range overflow flag of the 2xf16 path
     unsigned* h_flag = nullptr;   // pinned copy
     bool exact = g_exact_fp32;    // fp32 kernels only
+    // K-loop schedules of the 2xf16 kernels (conv_split.h SplitStep), built on first use per (kernel, layer shape) and kept
+    // on the device for the life of the ctx: (kernel, key) -> device table
+    std::vector<std::pair<std::pair<const SplitKernelInfo*, SplitPlanKey>, SplitStep*>> split_plans;
     // profiling
     int prof = 0;                 // 0 off, 1 every launch, 2 conv launches of >= 20 GFLOP only (cheap enough for timed runs)
     bool prof_open = false;
@@ -1175,6 +1178,24 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
 
+// the K-loop schedule of this launch (SplitArgs::plan): tile-invariant, so one table per (kernel, cells, sources) serves every
+// launch of the layer; the first launch builds and uploads it (a blocking copy, once)
+static const SplitStep* split_plan(tpz_ctx* ctx, const SplitKernelInfo& ks, const SplitArgs& a) {
+    SplitPlanKey k;
+    memset(&k, 0, sizeof k);
+    k.cells_in = a.cells_in; k.cells_in1 = a.cells_in1; k.n_chunks = a.n_chunks; k.has_in2 = a.in2 != nullptr;
+    k.vol = (a.KZ > 1 || a.Din > 1) ? 1 : 0; k.KZ = a.KZ; k.fold_cells = a.fold_cells; k.fold_tap = a.fold_tap;
+    for (auto& e : ctx->split_plans)
+        if (e.first.first == &ks && memcmp(&e.first.second, &k, sizeof k) == 0) return e.second;
+    std::vector<SplitStep> h;
+    ks.make_plan(k, h);
+    SplitStep* d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(SplitStep)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(SplitStep), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    ctx->split_plans.push_back({{&ks, k}, d});
+    return d;
+}
+
 static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, int n_cog, double flops) {
     if (a.wy1 < 0) {
         a.wy1 = -a.wy1;
@@ -1198,6 +1219,8 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32))
         return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
     dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
+    a.plan = split_plan(ctx, ks, a);
+    if (!a.plan) return fail(ctx, "out of device memory (K-loop plan)");
     prof_begin(ctx, 0, flops, ks.name);
     hipError_t e = ks.launch(a, grid, ctx->stream);
     prof_end(ctx);
@@ -1817,6 +1840,7 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipFree(ctx->d_zeros);
     (void)hipFree(ctx->d_flag);
     (void)hipHostFree(ctx->h_flag);
+    for (auto& e : ctx->split_plans) (void)hipFree(e.second);
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

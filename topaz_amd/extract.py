@@ -174,6 +174,8 @@ class ImageFeed:
         self.ready: 'queue.Queue' = queue.Queue(maxsize=self.DEPTH - 1)
         self.free: 'queue.Queue' = queue.Queue()
         self.thread = threading.Thread(target=self._reader, daemon=True)
+        self._retired: List['rt.Stage'] = []      # outgrown rings: closed by the consumer when the feed ends
+        self._stop = threading.Event()           # the consumer left (done, or an exception): the reader must not block
 
     def _ensure_stage(self, nbytes: int) -> None:
         # (called from the reader thread before any slot of a new, larger ring is handed out)
@@ -185,7 +187,27 @@ class ImageFeed:
                 self.free.get_nowait()
             for k in range(self.DEPTH):
                 self.free.put((self.stage, k))
-            self._retired = old            # freed when the feed ends (its slots may still be in flight)
+            if old is not None:
+                self._retired.append(old)  # closed by the consumer when the feed ends (never from this thread: tpz_stage_free
+                                           # synchronises the ctx stream the consumer is enqueuing on)
+
+    def _get_free(self):
+        """a free slot, or None once the consumer has left"""
+        while not self._stop.is_set():
+            try:
+                return self.free.get(timeout=0.1)
+            except queue.Empty:
+                pass
+        return None
+
+    def _put_ready(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self.ready.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def _reader(self) -> None:
         try:
@@ -197,16 +219,24 @@ class ImageFeed:
                     # wait until every slot of the old ring came back, then grow
                     if self.stage is not None:
                         for _ in range(self.DEPTH):
-                            self.free.get()
+                            if self._get_free() is None:
+                                return
                     self._ensure_stage(nbytes)
-                stage, k = self.free.get()
+                slot = self._get_free()
+                if slot is None:
+                    return
+                stage, k = slot
+                # the slot's previous upload may still be queued (a consumer that only enqueues runs ahead of the copy
+                # stream): the pinned buffer is refilled only after that copy has read it
+                stage.wait(k)
                 host = stage.host_array(k, image.shape)
                 np.copyto(host, image, casting='unsafe')                  # decode/convert straight into pinned memory
                 stage.upload(k, nbytes)
-                self.ready.put((path, stage, k, image.shape))
-            self.ready.put(None)
+                if not self._put_ready((path, stage, k, image.shape)):
+                    return
+            self._put_ready(None)
         except BaseException as e:                                            # surface reader failures in the consumer
-            self.ready.put(e)
+            self._put_ready(e)
 
     def __iter__(self) -> Iterator[Tuple[str, torch.Tensor]]:
         self.thread.start()
@@ -229,6 +259,18 @@ class ImageFeed:
         finally:
             if held is not None:
                 held[0].release(held[1])
+            # the consumer is leaving (exhausted, early exit or exception): unblock and join the reader, then close the rings
+            # from THIS thread (the one that enqueues on the ctx stream)
+            self._stop.set()
+            if self.thread.is_alive():
+                self.thread.join(timeout=30)
+            if not self.thread.is_alive():
+                for st in self._retired:
+                    st.close()
+                self._retired = []
+                if self.stage is not None:
+                    self.stage.close()
+                    self.stage = None
 
 
 class Scorer:

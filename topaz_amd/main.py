@@ -24,7 +24,26 @@ def main(argv=None):
         # command shards its input list over the ranks (parallel.shard_indices), extract gathers the pick tables
         from . import parallel
         cmd = [sys.executable, '-m', 'topaz_amd'] + list(sys.argv[1:] if argv is None else argv)
-        return parallel.launch_local_ranks(n, cmd)
+        listfile = None
+        if hasattr(args, 'paths') and len(args.paths) == 0:
+            # the input list comes from stdin (extract.py:352 of this package; topaz/extract.py:270): N ranks sharing one stdin
+            # would each consume a different part of it and take THAT for the whole list.  The launcher reads it once and
+            # hands every rank the same list through an @file argument (argparse expands it: main.py:55 upstream).
+            import tempfile
+            names = [ln.strip() for ln in sys.stdin if ln.strip()]
+            if not names:
+                parser.error('no input files (none on the command line, none on stdin)')
+            fd = tempfile.NamedTemporaryFile('w', prefix='topaz_inputs_', suffix='.txt', delete=False)
+            fd.write('\n'.join(names) + '\n')
+            fd.close()
+            listfile = fd.name
+            cmd.append('@' + listfile)
+        try:
+            return parallel.launch_local_ranks(n, cmd)
+        finally:
+            if listfile:
+                import os
+                os.unlink(listfile)
     return args.func(args)
 
 

@@ -63,7 +63,7 @@ def _allowed(module: str, name: str) -> bool:
         return True
     if module == 'torch' and (name.endswith(_ALLOWED_TORCH_SUFFIX) or name in _TORCH_DTYPES):
         return True
-    if module == 'torch.storage' and name in ('UntypedStorage', 'TypedStorage', '_load_from_bytes'):
+    if module == 'torch.storage' and name in ('UntypedStorage', 'TypedStorage'):
         return True
     # layer classes: plain attribute containers, instantiated via __reduce__ / __setstate__ only
     if module.startswith('torch.nn.modules.') and name[:1].isupper() and name.isidentifier():
@@ -71,10 +71,19 @@ def _allowed(module: str, name: str) -> bool:
     return False
 
 
+def _load_from_bytes(b):
+    """torch.storage._load_from_bytes is torch.load(BytesIO(b), weights_only=False) with the STANDARD unpickler: a nested
+    payload would escape the allowlist.  The same bytes through this module's own unpickler instead."""
+    import io
+    return torch.load(io.BytesIO(b), map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == 'topaz' or module.startswith('topaz.'):
             return _stub_for(module, name)
+        if (module, name) == ('torch.storage', '_load_from_bytes'):
+            return _load_from_bytes
         if not _allowed(module, name):
             raise pickle.UnpicklingError(f'model file refers to {module}.{name}, which a topaz model pickle has no '
                                          f'business loading (allowlist: topaz_amd/model/unpickle.py)')

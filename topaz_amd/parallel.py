@@ -61,7 +61,8 @@ def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, 
     procs = []
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(list(argv), env=e))
+        # (stdin is not shared: N readers of one pipe would each see a part of it -- the launcher resolves stdin input itself)
+        procs.append(subprocess.Popen(list(argv), env=e, stdin=subprocess.DEVNULL))
     t0 = time.time()
     codes: List[Optional[int]] = [None] * n
     try:
