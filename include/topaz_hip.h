@@ -196,11 +196,14 @@ int tpz_maxpool2(tpz_ctx* ctx, int dims, const float* d_in, int C, int D, int H,
 int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float* d_out);
 
 /* ---- introspection / measurement --------------------------------------------------------- */
-/* ---- 2xf16 path.  Scoring networks (1-channel stem, single-source 2-D convs, fused head) run by default on the
- * f16 matrix cores with every fp32 operand carried as two f16 halves and three exact products accumulated in fp32
- * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  An activation beyond
- * the f16 range is detected on the device and that image is re-run on the fp32 kernels, so results never depend
- * on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1 in the environment) pins the fp32 kernels.
+/* ---- 2xf16 path.  Every convolution with a conv_split kernel -- the scoring networks (stem as a column kernel, dilated
+ * 3x3 / 5x5 layers, folded 1x1 projections, fused head), the 2-D U-Nets / FCNN (encoders with fused max-pool, per-parity and
+ * sub-pixel decoders, the 1-output-channel last conv as a column kernel) and the 3-D U-Net (plane-stacked) -- runs by default on
+ * the f16 matrix cores with every fp32 operand carried as two f16 halves and three exact products accumulated in fp32
+ * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  3-D scoring networks and layers with
+ * a PReLU slope > 1 stay on the fp32-MFMA kernels.  An activation beyond the f16 range is detected on the device and that
+ * image is re-run on the fp32 kernels, so results never depend on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1
+ * in the environment) pins the fp32 kernels.
  * tpz_model_split_stats: whether the model is eligible, images finished on the 2xf16 path, images re-run in fp32. */
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
 /* Patch lanes: tpz_denoise_2d / _3d enqueue the independent patches / tiles of an image alternately on two auxiliary

@@ -120,3 +120,27 @@ def test_average_precision_and_matching():
     p = np.array([[11, 10], [80, 80], [49, 52]])
     a, d = match_coordinates(t, p, 5)
     assert a.tolist() == [1, 0, 1] and abs(d[0] - 1) < 1e-9
+
+
+def test_via_csv_region_table():
+    """`--format csv`: VGG Image Annotator regions (utils/files.py:109-146 upstream) -- per-image pick count and running index,
+    JSON point and score.  Expected text written by the reference's write_via_csv for this table."""
+    import io
+    import numpy as np
+    import pandas as pd
+    from topaz_amd.utils.files import write_via_csv
+    t = pd.DataFrame({'image_name': ['b', 'a', 'b', 'c', 'a'], 'x_coord': [44, 47, 64, 67, 67], 'y_coord': [87, 70, 88, 88, 12],
+                      'score': np.array([-2.5, 0.25, -0.5, 1.0, 3.0], dtype=np.float32)})
+    out = io.StringIO()
+    write_via_csv(out, t)
+    assert out.getvalue().splitlines() == [
+        'filename,file_size,file_attributes,region_count,region_id,region_shape_attributes,region_attributes',
+        'b.png,-1,{},2,0,"{""name"":""point"",""cx"":44,""cy"":87}","{""score"":""-2.5""}"',
+        'a.png,-1,{},2,0,"{""name"":""point"",""cx"":47,""cy"":70}","{""score"":""0.25""}"',
+        'b.png,-1,{},2,1,"{""name"":""point"",""cx"":64,""cy"":88}","{""score"":""-0.5""}"',
+        'c.png,-1,{},1,0,"{""name"":""point"",""cx"":67,""cy"":88}","{""score"":""1.0""}"',
+        'a.png,-1,{},2,1,"{""name"":""point"",""cx"":67,""cy"":12}","{""score"":""3.0""}"',
+    ]
+    out = io.StringIO()
+    write_via_csv(out, t.drop(columns='score'))
+    assert out.getvalue().splitlines()[1] == 'b.png,-1,{},2,0,"{""name"":""point"",""cx"":44,""cy"":87}",{}'

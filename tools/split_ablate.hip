@@ -42,7 +42,7 @@ float run(const SplitArgs& a, dim3 grid, int iters) {
     return ms / iters;
 }
 
-static bool g_lat = false;
+static bool g_lat = false, g_exp = false;
 template <class C, int EPI>
 int bench(const char* name, int cin, int cout, int H) {
     const int span = C::D * (C::K - 1);
@@ -81,6 +81,20 @@ int bench(const char* name, int cin, int cout, int H) {
            n_st * a.cog_inner);
 #define RUN(ABL, label) { hipMemset(flag, 0, 64); float ms = run<C, EPI, (ABL) | 2048>(a, grid, 6); unsigned long long c[4]; hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost); \
     printf("  %-52s %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", label, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0); }
+    if (g_exp) {
+        // round-3 experiments on the plan-driven K loop: DMA form, where in the step the DMA is issued, order of fragment 0
+        for (int ih = 0; ih < (C::ISSUER_HALF ? 2 : 1); ++ih) {
+            a.issuer_half = ih;
+            printf(" issuer_half = %d\n", ih);
+            RUN(0, "baseline (buffer DMA, issued at the top of the step)");
+            RUN(65536, "round-2 DMA forms (global_load_lds)");
+            RUN(131072, "fragment 0: MFMAs first, then the A(1) request");
+            RUN(262144, "DMA issued mid-step");
+            RUN(262144 | 131072, "DMA mid-step + fragment 0 MFMAs first");
+            RUN(0, "baseline (again)");
+        }
+        return 0;
+    }
     if (g_lat) {
         // short list: what the DMA costs, split into issue and waiting for arrival
         if (C::WAVES == 8 && C::MT >= 96) a.issuer_half = 1;           // as the library launches it
@@ -205,6 +219,17 @@ int main(int argc, char** argv) {
         bench<SplitCfg<3, 4, 128, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT128 8w S=2 RES cin=64", 64, 128, 2048);
         bench<SplitCfg<3, 8, 128, 16, 32, 2, 8, 3, 1>, EPI_RES>("K3 D8 MT128 8w RES", 128, 128, 2048);
         bench<SplitCfg<5, 4, 128, 16, 32, 2, 8, 5, 1>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "exp") {
+        g_exp = true;
+        bench<SplitCfg<5, 4, 128, 16, 32, 2, 8, 5, 1>, EPI_HEAD>("K5 D4 MT128 HEAD", 128, 256, 2048);
+        bench<SplitCfg<3, 8, 128, 16, 32, 2, 8, 3, 1>, EPI_RES>("K3 D8 MT128 8w RES", 128, 128, 2048);
+        bench<SplitCfg<3, 4, 128, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D4 MT128 8w S=2", 128, 128, 2048);
+        bench<SplitCfg<3, 2, 64, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D2 MT64 4w", 64, 64, 2048);
+        bench<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w S=2 RES", 64, 64, 2048);
+        bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
+        bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "ab") {

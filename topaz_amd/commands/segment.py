@@ -13,31 +13,43 @@ def add_arguments(parser=None):
     return build_parser(SEGMENT, help, parser)
 
 
-def segment_images(model, paths, output_dir, use_cuda, verbose, patch_size=None):
+class MapSink:
+    """where score maps go: <destdir>/<micrograph name>.tiff (float32, 2-D) or .npy (volumes) -- model/utils.py:96-105"""
+
+    def __init__(self, destdir: str, verbose: bool):
+        os.makedirs(destdir, exist_ok=True)
+        self.destdir, self.verbose = destdir, verbose
+
+    def write(self, source_path: str, scores: np.ndarray) -> str:
+        stem = os.path.join(self.destdir, os.path.splitext(os.path.basename(source_path))[0])
+        if self.verbose:
+            print('# saving:', stem)
+        if scores.ndim == 3:
+            np.save(stem + '.npy', scores)
+            return stem + '.npy'
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(scores, dtype=np.float32)).save(stem + '.tiff', 'tiff')
+        return stem + '.tiff'
+
+
+def score_map(model, pixels: np.ndarray, patch_size=None) -> np.ndarray:
+    """per-pixel (per-voxel) logits of one micrograph / tomogram: the filled model over the whole array or, with `patch_size`,
+    over tiles of twice that size that overlap by the receptive field (the evident intent of model/utils.py:88-90, which passes
+    predict_in_patches a keyword it does not take and crashes upstream -- SURVEY 3.1)"""
     from ..model.utils import predict_in_patches
+    x = torch.as_tensor(np.ascontiguousarray(pixels), dtype=torch.float32)[None, None]
+    if patch_size is not None:
+        return predict_in_patches(model, x, patch_size=2 * patch_size, is_3d=(pixels.ndim == 3), use_cuda=True)[0, 0]
+    with torch.no_grad():
+        return model(x.cuda())[0, 0].cpu().numpy()
+
+
+def segment_images(model, paths, output_dir, use_cuda, verbose, patch_size=None):
+    """topaz.model.utils.segment_images (model/utils.py:71-105): one score map file per input"""
     from ..utils.image import load_image
-    os.makedirs(output_dir, exist_ok=True)
+    sink = MapSink(output_dir, verbose)
     for path in paths:
-        image_name = os.path.splitext(os.path.basename(path))[0]
-        image = load_image(path, make_image=False, return_header=False)
-        is_3d = image.ndim == 3
-        with torch.no_grad():
-            X = torch.from_numpy(np.array(image)).float().unsqueeze(0).unsqueeze(0)
-            if patch_size is not None:
-                # (the reference passes an unsupported keyword here and crashes; this is the
-                #  evident intent: patches of 2*patch_size with width//2 overlap)
-                score = predict_in_patches(model, X, patch_size=patch_size * 2, is_3d=is_3d, use_cuda=True)
-            else:
-                score = model(X.cuda()).cpu().numpy()
-            score = score[0, 0]
-        out = os.path.join(output_dir, image_name)
-        if verbose:
-            print('# saving:', out)
-        if is_3d:
-            np.save(out + '.npy', score)
-        else:
-            from PIL import Image
-            Image.fromarray(np.asarray(score, dtype=np.float32)).save(out + '.tiff', 'tiff')
+        sink.write(path, score_map(model, load_image(path, make_image=False, return_header=False), patch_size))
 
 
 def main(args):

@@ -368,7 +368,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const int ybase = y0 - pad_y, xbase = x0 - pad_x;
     const bool vol = VOLM && (a.KZ > 1 || a.Din > 1);        // plane-stacked 3-D addressing
 
-    constexpr unsigned OOB = 0xffffffffu;
+    // marks a cell outside the image / past the last channel.  16-byte aligned: as the offset of a buffer load all four of its
+    // dwords lie outside every descriptor (no 32-bit wrap), and the hardware then writes ZEROS to the LDS -- checked on the
+    // MI355X by tools/bufdma_probe.hip (the range check is per dword)
+    constexpr unsigned OOB = 0xfffffff0u;
+    // how the LDS-DMA is issued: buffer loads (descriptor per chunk and plane, 32-bit lane offsets straight from the table,
+    // out-of-range lanes zero-filled by the hardware) or, ABL 65536, the round-2 global_load_lds forms
+    constexpr bool BUFDMA = (ABL & 65536) == 0;
     // ---- the chunk-invariant global byte offset of every LDS cell of a source
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
     // (tid and the sizes nearest_src() divides are passed in: the co-group loop hands over opaque copies, so that nothing of this prologue is
@@ -418,6 +424,16 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
                                          (__attribute__((address_space(3))) void*)(size_t)lds_addr, 16, 0, 0);
     };
+    //  * (round 3, the default) buffer loads: a descriptor per (chunk, plane) built from scalars, the table entry as the 32-bit
+    //    lane offset, cells outside the image carry the offset OOB and come back as zeros -- no zero block, no per-lane
+    //    pointers, no divergent paths: table read + 2 instructions per round.
+    auto make_srd = [&](const void* base, size_t bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(base)), 0,
+                                                 (int)__builtin_amdgcn_readfirstlane((unsigned)bytes), 0x00020000);
+    };
+    auto bdma16 = [&](__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff, unsigned lds_addr) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(size_t)lds_addr, 16, voff, soff, 0, 0);
+    };
     // The rounds `rounds` (bit r) of the input tile of the chunk that plan entry P describes -> its input buffer (both planes);
     // (tid, wave): whose share.  Everything but the table lookup and the DMA itself is scalar.
     auto fetch = [&](const StepW& P, unsigned rounds, int tid, int wave) {
@@ -428,6 +444,9 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const uint4* chunk = second ? in2 + (size_t)P[3] * (C::CC * hw2) : a.in + (size_t)P[3] * (C::CC * (size_t)a.H1 * a.W1);
         const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
         const size_t lo_delta0 = (second ? plane2 : plane1) * 16;       // bytes from a hi cell to its lo cell
+        // buffer descriptors: the chunk's CC cell planes (2-D) or one half of the whole tensor (plane-stacked 3-D), hi and lo
+        const size_t ext = vol ? plane1 * 16 : (second ? (size_t)C::CC * hw2 : (size_t)C::CC * a.H1 * a.W1) * 16;
+        const __amdgpu_buffer_rsrc_t srd_hi = make_srd(bhi, ext), srd_lo = make_srd(bhi + lo_delta0, ext);
         // plane-stacked 3-D: virtual cell v = kz * cells + c of the chunk is cell c of input plane oz + kz - pad_z, of `in` or
         // `in2` (32-bit byte offsets from the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
         constexpr int CCV = C::CC < 4 ? C::CC : 4;
@@ -461,7 +480,22 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     else if (off != OOB) { off += co; lane2 = HAS2 && (cf & 2u) != 0; }
                 }
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
-                if constexpr (C::UNIFORM_DMA) {
+                if constexpr (BUFDMA) {
+                    if (VOLM && HAS2 && __any(lane2)) {
+                        // (plane-stacked 3-D with a second source: the lanes of a wave may straddle cells of both tensors)
+                        if (lane2) {
+                            const __amdgpu_buffer_rsrc_t s2h = make_srd(in2, plane2 * 16), s2l = make_srd(in2 + plane2, plane2 * 16);
+                            bdma16(s2h, off, 0, dst);
+                            bdma16(s2l, off, 0, dst + C::PLANE_BYTES);
+                        } else {
+                            bdma16(srd_hi, off, 0, dst);
+                            bdma16(srd_lo, off, 0, dst + C::PLANE_BYTES);
+                        }
+                    } else {
+                        bdma16(srd_hi, off, 0, dst);
+                        bdma16(srd_lo, off, 0, dst + C::PLANE_BYTES);
+                    }
+                } else if constexpr (C::UNIFORM_DMA) {
                     const void* blo = bhi + lo_delta;
                     if (!__any(off == OOB || lane2)) {
                         glds_b128(off, bhi, dst);
@@ -496,6 +530,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     auto issue_weights = [&](const unsigned char* wcog, int stg, int bytes, int buf, int tid, int wave) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>(uniform_ptr(wcog + (size_t)stg * C::W_STAGE_BYTES));
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_W + buf * C::W_STAGE_BYTES + wave * 1024));
+        if constexpr (BUFDMA) {
+            const __amdgpu_buffer_rsrc_t srd = make_srd(base, (size_t)bytes);
+#pragma unroll
+            for (int i = 0; i < C::WR; ++i)
+                if ((i * C::WAVES + wave) * 1024 < bytes) bdma16(srd, (unsigned)tid * 16u, (unsigned)(i * C::THREADS * 16), dst + i * C::THREADS * 16);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < C::WR; ++i)
             if ((i * C::WAVES + wave) * 1024 < bytes) {                // whole waves (1 KiB each)
@@ -575,6 +616,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             // the next step's plan entry: requested now, first used behind this step's barrier
             const StepW Pn = plan[1 + (s + 1 < n_stages ? s + 1 : s)];
             // ---- prefetch by DMA: the weights of the next stage, a share of the next chunk's input tile
+            auto step_dma = [&]() {
             if (!(ABL & 2) && sub == 0) {
                 // issuer_half: the upper four waves issue every piece of the step (their SIMD partners, waves w - 4,
                 // start their MFMAs at once and keep the matrix core busy meanwhile)
@@ -600,6 +642,12 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     }
                 }
             }
+            };
+            // where in the step it is issued: at the top (every wave issues its pieces before its first MFMA), or, DMA_AT > 0,
+            // between the MFMAs of channel fragments DMA_AT - 1 and DMA_AT
+            constexpr int DMA_AT = ((ABL & 262144) && MW >= 2) ? (MW >= 4 ? MW / 2 : 1) : 0;
+            constexpr bool MFMA_FIRST = (ABL & 131072) != 0;       // fragment 0: first NW MFMAs, then the A(1) request
+            if constexpr (DMA_AT == 0) step_dma();
             // ---- the step's MFMAs, register-pipelined across the step barrier:
             //   channel fragments 0 .. MW-2 (A(m + 1) requested one fragment ahead), then the DMA drain + barrier, then the
             //   MFMAs of the last channel fragment -- which need registers only -- interleaved with the requests for the
@@ -614,6 +662,25 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const int t = m & 1;
+                if (DMA_AT > 0 && m == DMA_AT && MW > 1) {
+                    // pin the fragments so far, then the step's DMA between two scheduling barriers
+                    if constexpr (!(ABL & 16) && !(ABL & 8)) {
+#pragma unroll
+                        for (int mm = 0; mm < DMA_AT; ++mm) {
+                            if (mm == 0 && MFMA_FIRST) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, NW, 2);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NW, 2);
+                            } else {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);         // A(mm + 1)
+                                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 2);    // MFMAs of mm
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    step_dma();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (m + 1 < MW) {
                     if constexpr (!(ABL & 8)) {
                         ah[t ^ 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
@@ -628,9 +695,15 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     // LDS latencies per step)
                     if constexpr (!(ABL & 16) && !(ABL & 8)) {
 #pragma unroll
-                        for (int mm = 0; mm + 1 < MW; ++mm) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // A(mm + 1)
-                            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);    // MFMAs of mm
+                        for (int mm = (DMA_AT < MW ? DMA_AT : 0); mm + 1 < MW; ++mm) {
+                            if (mm == 0 && MFMA_FIRST) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, NW, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NW, 0);
+                            } else {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // A(mm + 1)
+                                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 0);    // MFMAs of mm
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);

@@ -1214,9 +1214,9 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     if (a.tiles_y > 65535 || gz > 65535) return fail(ctx, "conv grid too large");
     // the LDS-DMA addresses are 32-bit byte offsets from a wave-uniform base: a chunk of cells (2-D) or one half of the
     // whole tensor (plane-stacked 3-D) must stay below 4 GiB
-    if (a.Din > 1 && (size_t)a.cells_in * a.Din * a.Hin * a.Win * 16 >= ((size_t)1 << 32))
+    if (a.Din > 1 && (size_t)a.cells_in * a.Din * a.Hin * a.Win * 16 >= ((size_t)1 << 32) - 16)
         return fail(ctx, "3-D tensor too large for the plane-stacked 2xf16 kernel (tile the volume)");
-    if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32))
+    if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32) - 16)
         return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
     dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
     a.plan = split_plan(ctx, ks, a);

@@ -25,51 +25,44 @@ def insize_from_outsize(layers, outsize):
     return outsize
 
 
+def tile_origins(shape, step: int):
+    """origins of the tile grid over an image / volume of `shape` = ([D,] H, W): rows outermost, then columns, then -- for a
+    volume -- planes, which is the order both the cutting and the stitching side walk (model/utils.py:151-166, 181-191)"""
+    if len(shape) == 2:
+        return [(None, i, j) for i in range(0, shape[0], step) for j in range(0, shape[1], step)]
+    return [(k, i, j) for i in range(0, shape[1], step) for j in range(0, shape[2], step) for k in range(0, shape[0], step)]
+
+
+def _window(t, origin, size):
+    """the (at most) size^dims window of tensor / array `t` at `origin`, clipped by slicing at the far edges"""
+    k, i, j = origin
+    if k is None:
+        return t[..., i:i + size, j:j + size]
+    return t[..., k:k + size, i:i + size, j:j + size]
+
+
 def get_patches(X: torch.Tensor, patch_size: int, patch_padding: int = 0, is_3d: bool = False) -> List[torch.Tensor]:
-    y, x = X.shape[-2:]
-    z = X.shape[-3] if is_3d else None
-    pad = (patch_padding, patch_padding) * (3 if is_3d else 2)
-    X = torch.nn.functional.pad(X, pad)
-    y_pad, x_pad = X.shape[-2:]
-    z_pad = X.shape[-3] if is_3d else None
-    step = patch_size - 2 * patch_padding
-    patches = []
-    for i in range(0, y, step):
-        for j in range(0, x, step):
-            i_end, j_end = min(i + patch_size, y_pad), min(j + patch_size, x_pad)
-            if is_3d:
-                for k in range(0, z, step):
-                    k_end = min(k + patch_size, z_pad)
-                    patch = X[..., k:k_end, i:i_end, j:j_end]
-                    if patch.abs().sum() == 0:
-                        continue
-                    patches.append(patch)
-            else:
-                patch = X[..., i:i_end, j:j_end]
-                if patch.abs().sum() == 0:
-                    continue
-                patches.append(patch)
-    return patches
+    """tiles of `patch_size` cut from X zero-padded by `patch_padding` on every side, at stride patch_size - 2 * padding
+    over the UNPADDED extent (model/utils.py:133-169).  Tiles that hold nothing but zeros are left out, as upstream."""
+    dims = 3 if is_3d else 2
+    padded = torch.nn.functional.pad(X, (patch_padding,) * (2 * dims))
+    tiles = (_window(padded, o, patch_size) for o in tile_origins(tuple(X.shape[-dims:]), patch_size - 2 * patch_padding))
+    return [t for t in tiles if bool(t.ne(0).any())]
 
 
 def reconstruct_from_patches(patches, original_shape, patch_size, patch_padding=0, is_3d=False) -> np.ndarray:
-    y, x = original_shape[-2:]
-    z = original_shape[-3] if is_3d else None
-    step = patch_size - patch_padding * 2
-    out = np.zeros(original_shape)                 # float64, like the reference
-    idx = 0
-    for i in range(0, y, step):
-        for j in range(0, x, step):
-            if is_3d:
-                for k in range(0, z, step):
-                    p = patches[idx]
-                    out[..., k:k + p.shape[-3], i:i + p.shape[-2], j:j + p.shape[-1]] = p
-                    idx += 1
-            else:
-                p = patches[idx]
-                out[..., i:i + p.shape[-2], j:j + p.shape[-1]] = p
-                idx += 1
-    return out
+    """float64 array of `original_shape` with patch n pasted at the n-th origin of the same grid (model/utils.py:172-193);
+    a patch list shortened by get_patches' zero-tile rule runs out here (IndexError), as upstream."""
+    dims = 3 if is_3d else 2
+    canvas = np.zeros(original_shape)
+    for n, origin in enumerate(tile_origins(tuple(original_shape[-dims:]), patch_size - 2 * patch_padding)):
+        piece = patches[n]
+        k, i, j = origin
+        if k is None:
+            canvas[..., i:i + piece.shape[-2], j:j + piece.shape[-1]] = piece
+        else:
+            canvas[..., k:k + piece.shape[-3], i:i + piece.shape[-2], j:j + piece.shape[-1]] = piece
+    return canvas
 
 
 def predict_in_patches(model, X: torch.Tensor, patch_size: int, is_3d: bool = False, use_cuda: bool = True) -> np.ndarray:
@@ -88,13 +81,11 @@ def predict_in_patches(model, X: torch.Tensor, patch_size: int, is_3d: bool = Fa
     step = patch_size - 2 * pad
     if step <= 0:
         raise ValueError(f'patch_size {patch_size} does not exceed the receptive field {model.width}')
-    starts = [(i, j, k) for i in range(0, shape[-2], step) for j in range(0, shape[-1], step)
-              for k in (range(0, shape[-3], step) if is_3d else (None,))]
+    starts = tile_origins(shape, step)
     scored = []
-    for (i, j, k) in starts:
-        tile = padded[..., i:i + patch_size, j:j + patch_size] if k is None else \
-            padded[..., k:k + patch_size, i:i + patch_size, j:j + patch_size]
-        if float(tile.abs().sum()) == 0:
+    for origin in starts:
+        tile = _window(padded, origin, patch_size)
+        if not bool(tile.ne(0).any()):
             continue                                       # get_patches drops all-zero tiles
         with torch.no_grad():
             s = model(tile.contiguous())[0, 0]
@@ -104,7 +95,7 @@ def predict_in_patches(model, X: torch.Tensor, patch_size: int, is_3d: bool = Fa
         # upstream stitches patches[idx] for every slot of the grid and runs past the end of the kept tiles
         raise IndexError('list index out of range (an all-zero tile was skipped: topaz/model/utils.py:159,181-191)')
     out = torch.zeros(tuple(X.shape), dtype=torch.float64, device=dev)
-    for (i, j, k), s in zip(starts, scored):
+    for (k, i, j), s in zip(starts, scored):
         if k is None:
             out[..., i:i + s.shape[-2], j:j + s.shape[-1]] = s
         else:

@@ -39,24 +39,21 @@ def write_star(table, f):
 
 
 def write_via_csv(path, table):
-    filename = table['image_name'].apply(lambda x: x + '.png')
-    via = pd.DataFrame({'filename': filename})
-    via['file_size'] = -1
-    via['file_attributes'] = '{}'
-    via['region_count'] = 0
-    via['region_id'] = 0
-    for im, group in table.groupby('image_name'):
-        where = via['filename'] == im + '.png'
-        via.loc[where, 'region_count'] = len(group)
-        via.loc[where, 'region_id'] = np.arange(len(group))
-    via['region_shape_attributes'] = ['{{"name":"point","cx":{},"cy":{}}}'.format(table['x_coord'].iloc[i],
-                                                                                 table['y_coord'].iloc[i])
-                                      for i in range(len(table))]
-    if 'score' in table.columns:
-        via['region_attributes'] = ['{{"score":"{}"}}'.format(table['score'].iloc[i]) for i in range(len(table))]
-    else:
-        via['region_attributes'] = '{}'
-    via.to_csv(path, index=False)
+    """VGG Image Annotator region CSV, one point region per pick (utils/files.py:109-146 upstream): per row the image as
+    `<name>.png`, the number of picks of that image and the pick's running index within it, the point as a JSON shape and
+    the score as a JSON attribute."""
+    per_image = table.groupby('image_name', sort=False)['image_name']
+    point = '{{"name":"point","cx":{},"cy":{}}}'.format
+    rows = {
+        'filename': table['image_name'].astype(str) + '.png',
+        'file_size': -1,
+        'file_attributes': '{}',
+        'region_count': per_image.transform('size').to_numpy(),
+        'region_id': per_image.cumcount().to_numpy(),
+        'region_shape_attributes': [point(x, y) for x, y in zip(table['x_coord'], table['y_coord'])],
+        'region_attributes': ['{{"score":"{}"}}'.format(v) for v in table['score']] if 'score' in table.columns else '{}',
+    }
+    pd.DataFrame(rows, index=table.index).to_csv(path, index=False)
 
 
 def write_table(f, table, format='auto', boxsize=0, image_ext=''):
