@@ -48,6 +48,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0       # same table: BF16/FP16 MFMA, dense ("~2.5 P
 # conv_split kernels issue three f16 MFMAs per fp32-equivalent multiply-add (wh*xh + wh*xl + wl*xh), so their
 # ceiling in ALGORITHMIC (fp32-equivalent) FLOP/s is a third of the f16 peak
 SPLIT_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
+HBM_PEAK_BYTES = 8.0e12             # HBM3E peak (same guide); ~6.3e12 is what a copy kernel achieves
 
 
 def build_models(workload: str):
@@ -86,37 +87,46 @@ def _cpu_model() -> str:
 
 
 def cpu_baseline(models, args):
-    """The oracle (torch-CPU convs, C NMS) timed on this host.  Default: a bounded sample -- an SxS crop of micrograph
-    0 through the same stages, scaled to micrographs/s by the pixel counts the full workload processes (patched
-    denoising touches 3.0x the image).  --cpu-full: micrograph 0 itself at the full size with the
-    same patching (minutes of CPU time; nothing is scaled)."""
+    """The oracle (torch-CPU convs, C NMS) timed on this host.  Default: a bounded sample of the step's own units of work --
+    the denoiser on ONE full patch of the -s/-p tiling (2024^2 at the defaults; a 4096^2 micrograph is 16 such crops, 3.0x the
+    image), the scorer and the suppression on a --cpu-sample crop (2048^2) -- each scaled by the pixels the
+    whole micrograph pushes through that stage.  (Round 2 timed everything on a 1024^2 crop: oneDNN runs small images at a
+    lower rate, which read 25 % slow against the whole micrograph.)  --cpu-full: micrograph 0 itself, nothing scaled (minutes)."""
     from oracle import denoising as oden
     from oracle import nms as onms
     from oracle import scoring as oscoring
     full = args.cpu_full
-    S = args.size if full else args.cpu_sample
-    x = np.random.RandomState(1000).randn(args.size, args.size).astype(np.float32)[:S, :S].copy()
+    img = np.random.RandomState(1000).randn(args.size, args.size).astype(np.float32)
     threads = torch.get_num_threads()
     per_image = 0.0
     parts = {}
     full_px = float(args.size) ** 2
+    S = args.size if full else min(args.size, args.cpu_sample)
+    x = img[:S, :S].copy()
+    # (one small untimed call per network: primitive creation / thread pool start-up are not the workload)
     if 'denoise' in models:
         sd = models['denoise'][1]
-        t0 = time.time()
-        den = oden.denoise('unet', sd, x, args.patch_size, args.patch_padding) if full else oden.denoise('unet', sd, x, -1)
-        t = time.time() - t0
-        # pixels the full job pushes through the net with -s/-p patching
-        n_px = 0
-        for i in range(0, args.size, args.patch_size):
-            for j in range(0, args.size, args.patch_size):
-                h = min(args.size, i + args.patch_size + args.patch_padding) - max(0, i - args.patch_padding)
-                w = min(args.size, j + args.patch_size + args.patch_padding) - max(0, j - args.patch_padding)
-                n_px += h * w
+        oden.denoise('unet', sd, img[:256, :256].copy(), -1)
+        if full:
+            t0 = time.time(); x = oden.denoise('unet', sd, x, args.patch_size, args.patch_padding); t = time.time() - t0
+            per_image += t
+        else:
+            P = min(args.size, args.patch_size + 2 * args.patch_padding)
+            t0 = time.time(); x = oden.denoise('unet', sd, img[:P, :P].copy(), -1); t = time.time() - t0
+            S = P                              # the later stages see what they see in the step: a denoised image
+            # pixels the full job pushes through the net with -s/-p patching
+            n_px = 0
+            for i in range(0, args.size, args.patch_size):
+                for j in range(0, args.size, args.patch_size):
+                    h = min(args.size, i + args.patch_size + args.patch_padding) - max(0, i - args.patch_padding)
+                    w = min(args.size, j + args.patch_size + args.patch_padding) - max(0, j - args.patch_padding)
+                    n_px += h * w
+            per_image += t * n_px / float(P * P)
+            parts['denoise_patch'] = f'{P}x{P}'
         parts['denoise_s'] = round(t, 3)
-        per_image += t if full else t * n_px / (S * S)
-        x = den
     if 'score' in models:
         sd = models['score'][1]
+        oscoring.score('resnet8', sd, img[:256, :256].copy())
         t0 = time.time(); logit = oscoring.score('resnet8', sd, x); t = time.time() - t0
         parts['score_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
@@ -124,8 +134,8 @@ def cpu_baseline(models, args):
         parts['nms_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
     sample = (f'micrograph 0 at {S}x{S} (the whole workload of one step, nothing scaled), times {parts}' if full else
-              f'{S}x{S} crop of micrograph 0 through the oracle, times {parts} scaled by processed-pixel ratio to '
-              f'{args.size}x{args.size}')
+              f'a {S}x{S} crop of micrograph 0 (one patch of the denoise tiling) through the oracle, times {parts}, each stage '
+              f'scaled by the pixels a {args.size}x{args.size} micrograph pushes through it')
     return {'value': 1.0 / per_image, 'unit': 'micrographs/s', 'cores': threads, 'kind': 'port',
             'cpu': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
             'sample': sample + '; oracle = torch-CPU fp32 convs (oneDNN), C NMS'}
@@ -164,10 +174,16 @@ def dry_run(args, rank, world):
     tables = parallel.gather_pick_tables(ids, scs, cds, dev) if world > 1 else {i: None for i in ids}
     parallel.barrier(dev)
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    total = int(parallel.sum_over_ranks(float(args.steps), dev))
+    rccl_world = int(parallel.sum_over_ranks(1.0, dev))
+    rank_ms = parallel.gather_scalars(1e3 * dt / max(1, args.steps), dev)
     if rank == 0:
-        assert sorted(tables) == list(range(world * args.steps)), sorted(tables)
+        assert sorted(tables) == list(range(total)), sorted(tables)
         print(json.dumps({'dry_run': True, 'metric': 'none (plumbing check, no hot path)', 'value': None, 'n_gpus': world,
-                          'steps': args.steps, 'warmup': args.warmup, 'images_gathered': len(tables),
+                          'steps': args.steps, 'warmup': args.warmup, 'images_gathered': len(tables), 'scaling': args.scaling,
+                          'rccl_world': rccl_world,
+            'host_placement': {'rank0_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS'))}, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
                           'ms_per_step': 1e3 * dt / max(1, args.steps), 'backend': 'gloo'}))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -227,13 +243,17 @@ def main():
     ap.add_argument('--patch-padding', type=int, default=500)
     ap.add_argument('--radius', type=int, default=14)
     ap.add_argument('--threshold', type=float, default=-6.0)
-    ap.add_argument('--cpu-sample', type=int, default=1024)
+    ap.add_argument('--cpu-sample', type=int, default=2048)
     ap.add_argument('--cpu-full', action='store_true', help='cpu_baseline on one whole micrograph instead of a crop (minutes)')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the exact_fp32 and pcie_inclusive legs')
     ap.add_argument('--exact-steps', type=int, default=3)
     ap.add_argument('--dry-run', action='store_true', help='CPU-only plumbing check over gloo (no hot path, not a measurement)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="weak (default): every rank times --steps micrographs; strong: BASELINE config 4's FIXED job of --images "
+                         'micrographs is dealt i = rank (mod N) to the ranks (--steps is then ignored)')
+    ap.add_argument('--images', type=int, default=256, help='--scaling strong: micrographs of the whole job')
     args = ap.parse_args()
 
     from topaz_amd import parallel
@@ -242,6 +262,8 @@ def main():
         sys.exit(parallel.launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = parallel.init_from_env('gloo' if args.dry_run else None)
     assert world == args.gpus, f'WORLD_SIZE={world} but --gpus {args.gpus}'
+    if args.scaling == 'strong':
+        args.steps = len(parallel.shard_indices(args.images, rank, world))       # this rank's share of the fixed job
     if args.dry_run:
         return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
@@ -249,14 +271,18 @@ def main():
     from topaz_amd import runtime as rt
     ctx = rt.get_context(local_rank)
 
-    # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world)
-    n_img = args.steps + args.warmup
+    # the collective really spans the job's ranks: an all_reduce of ones over RCCL (1 without a process group)
+    rccl_world = int(parallel.sum_over_ranks(1.0, dev))
+    # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world); a long strong-scaling
+    # share cycles through a bounded set of resident micrographs
+    n_res = min(args.steps, 8) if args.scaling == 'strong' else args.steps
+    n_img = n_res + args.warmup
     host_imgs = [np.random.RandomState(1000 + rank + i * world).randn(args.size, args.size).astype(np.float32)
                  for i in range(n_img)]
     imgs = [torch.from_numpy(h).to(dev) for h in host_imgs]
     models = build_models(args.workload)
     for w in range(args.warmup):
-        run_step(models, imgs[args.steps + w], args)
+        run_step(models, imgs[n_res + w], args)
     torch.cuda.synchronize(dev)
     if not args.no_kernel_timing:
         # roofline evidence: HIP events around the convolution launches of the TIMED steps (those of >= 20 GFLOP: ~170 of
@@ -269,7 +295,7 @@ def main():
     torch.cuda.synchronize(dev)
     parallel.barrier(dev)
     t0 = time.perf_counter()
-    picks = [run_step(models, imgs[i], args) for i in range(args.steps)]
+    picks = [run_step(models, imgs[i % n_res], args) for i in range(args.steps)]
     torch.cuda.synchronize(dev)
     t_compute = time.perf_counter() - t0
     ids = [rank + i * world for i in range(args.steps)]
@@ -281,6 +307,10 @@ def main():
     t_gather = time.perf_counter() - t0 - t_compute
     parallel.barrier(dev)
     dt = time.perf_counter() - t0
+    # every rank's own compute time per micrograph: stragglers (host contention between the ranks' launch threads, a slow
+    # device) show as a spread between min and max
+    rank_ms = parallel.gather_scalars(1e3 * t_compute / max(1, args.steps), dev)
+    total_steps = int(parallel.sum_over_ranks(float(args.steps), dev))
     dt = parallel.max_over_ranks(dt, dev)
     t_gather = parallel.max_over_ranks(t_gather, dev)
     n_picks = int(sum(int(s.numel()) for s in scs)) if have_picks else 0
@@ -344,6 +374,30 @@ def main():
     cls_f32['frac'] = cls_f32['achieved'] / FP32_MFMA_PEAK_TFLOPS
     cls_split['frac'] = cls_split['achieved'] / SPLIT_PEAK_TFLOPS
 
+    # ---- the kernels that are HBM-bound rather than MFMA-bound (arithmetic intensity below the ridge of their MFMA peak:
+    # 1-channel stems, the 1-output-channel last conv and its shiftsum): algorithmic bytes / HIP-event time of ONE extra
+    # step with every launch timed and the patch lanes off, against the 8 TB/s of HBM3E
+    hbm_rows = []
+    if rank == 0 and not args.no_kernel_timing:
+        ctx.set_lanes(False)
+        try:
+            ctx.prof_enable(1)
+            ctx.prof_reset()
+            run_step(models, imgs[-1], args)
+            torch.cuda.synchronize(dev)
+            for nm, ms, n, fl, by in ctx.prof_kernels_bytes():
+                if by <= 0 or ms <= 0:
+                    continue
+                pk = SPLIT_PEAK_TFLOPS if nm.startswith('conv_split') else FP32_MFMA_PEAK_TFLOPS
+                if fl / by < pk * 1e12 / HBM_PEAK_BYTES:          # below the ridge: the roof is HBM
+                    hbm_rows.append({'kernel': nm, 'ms': ms, 'launches': n, 'algorithmic_gb': by / 1e9,
+                                     'achieved_gb_s': by / (ms * 1e-3) / 1e9, 'frac': by / (ms * 1e-3) / HBM_PEAK_BYTES,
+                                     'flop_per_byte': fl / by})
+            ctx.prof_enable(False)
+        finally:
+            ctx.set_lanes(True)
+        hbm_rows.sort(key=lambda r: -r['ms'])
+
     # ---- extra legs (after the timed region, N = 1 only): exact-fp32 kernels; host-resident input (PCIe-inclusive)
     extras = {}
     if world == 1 and not args.no_extras:
@@ -376,14 +430,18 @@ def main():
     if rank == 0:
         out = {
             'metric': 'micrographs/sec (4096x4096 fp32) denoise+score, NMS parity',
-            'value': world * args.steps / dt,
+            'value': total_steps / dt,
             'unit': 'micrographs/s',
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps,
+            'ms_per_step': 1e3 * dt / max(1, args.steps),
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
+            'rccl_world': rccl_world,
+            'host_placement': {'rank0_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS'))},
+            'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': [round(v, 3) for v in rank_ms]},
             'vs_baseline': None,
             'dtype': 'f32 (fp32 MFMA kernels only: TPZ_EXACT_FP32 is set)' if os.environ.get('TPZ_EXACT_FP32') else
                      'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
@@ -394,7 +452,7 @@ def main():
                 'workload': {'pipeline': 'denoise(unet b11/t5 nf48, -s 1024 -p 500) -> score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'extract': 'score(resnet8 u64, filled) -> NMS(r=14,t=-6)',
                              'denoise': 'denoise(unet b11/t5 nf48, -s 1024 -p 500)'}[args.workload],
-                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps,
+                'image': f'{args.size}x{args.size} fp32', 'images_per_rank': args.steps, 'images_total': total_steps,
                 'parallelism': f'one micrograph per rank x{world}; RCCL gather of pick tables',
                 'picks_per_image': n_picks / max(1, len(scs)) if have_picks else None,
                 'patch_windows': 'on: a denoise patch computes, layer by layer, only what its kept 1024^2 centre depends on '
@@ -420,6 +478,9 @@ def main():
                                 for k in kernels_iso[:6]],
                 'class_and_top_kernels_from': 'one extra step with the patch lanes off (kernels timed in isolation)',
                 **({} if not args.no_kernel_timing else other),
+                'hbm_bound_kernels': {'peak': HBM_PEAK_BYTES / 1e9, 'unit': 'GB/s', 'rows': hbm_rows[:6],
+                                      'from': 'one extra step, every launch timed, patch lanes off; bytes = inputs (with halo) + '
+                                              'weights read once, outputs written once'},
                 'coverage': ('convolution launches of >= 20 GFLOP (the rest, elementwise and NMS kernels are not timed inside '
                              'the timed region)' if not args.no_kernel_timing else 'every launch of one extra step'),
             },

@@ -217,6 +217,12 @@ int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
  * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
  * (TPZ_NO_ROI=1 in the environment or on = 0 here). */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
+/* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
+ * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next
+ * tile under the last chunk of the current one.  mode 0: never (TPZ_NO_PERSIST=1), 1: large launches outside the patch lanes
+ * (default), 2: every eligible launch, with `workgroups` of them (0: one grid slot each) -- the form the tests use to run
+ * small images through many tiles per workgroup.  Results are bit-identical in every mode. */
+int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups);
 int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns);
 /* One 2-D convolution on the 2xf16 kernels with fp32 [C][H][W] tensors at the boundary (converted on the device):
  * unit-test / interop entry; arguments as tpz_conv (single source).  *overflow = 1 when a result left the f16 range. */
@@ -239,6 +245,9 @@ int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double*
  * once rank runs past the instantiations that were launched */
 int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches, double* flops, char* name,
                         int name_len);
+/* algorithmic HBM bytes (inputs with halo + weights read once, outputs written once) of the launches behind
+ * tpz_prof_get_kernel(rank): the bandwidth of the kernels that are HBM-bound rather than MFMA-bound */
+int tpz_prof_get_kernel_bytes(tpz_ctx* ctx, int rank, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -187,14 +187,19 @@ def to_torch_sd(sd) -> Dict[str, torch.Tensor]:
 
 
 @torch.no_grad()
-def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = False, dropout: bool = False) -> np.ndarray:
+def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = False, dropout: bool = False,
+          dtype=torch.float32) -> np.ndarray:
     """logits of one [H,W] image (or [D,H,W] tomogram, with 3-D weights) with the filled network `arch` (what
     extract.py:247-249 computes).  dropout=True: `sd` is the state_dict of a model built with dropout > 0 (upstream's
-    numbering, Dropout modules included)."""
+    numbering, Dropout modules included).  dtype=torch.float64 evaluates the same fp32 weights and input in double precision
+    (the yardstick of the precision tests: how far is an fp32 evaluation from the exact result?)."""
     if num_threads:
         torch.set_num_threads(num_threads)
     sd = to_torch_sd(sd)
     xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None, None]
+    if dtype != torch.float32:
+        sd = OrderedDict((k, v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items())
+        xt = xt.to(dtype)
     if arch in ARCH_SPECS:
         spec = ARCH_SPECS[arch](pooling, dropout) if arch != 'resnet6' else resnet6_spec()
         fill(spec)

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU layer (sharding + the pick-table gather)."""
+"""gloo tests (world 2 and world 8) of the multi-GPU layer: sharding, the pick-table gather, the launcher, bench.py's ranks."""
 import os
 import socket
 
@@ -69,6 +69,20 @@ def test_gather_pick_tables_world2_gloo():
     assert q.get(timeout=5) is True
 
 
+def test_gather_pick_tables_world8_gloo():
+    """BASELINE config 4's shape: eight ranks, images dealt i = rank (mod 8), ragged tables (some empty), one gather"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, 37, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_gather_single_process():
     from topaz_amd.parallel import gather_pick_tables
     s, c = _tables(3)
@@ -92,6 +106,27 @@ def test_bench_self_launches_its_ranks_dry_run():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['images_gathered'] == 6 and out['dry_run'] is True
+    assert out['rccl_world'] == 2 and out['scaling'] == 'weak'
+
+
+def test_bench_eight_ranks_dry_run_weak_and_strong():
+    """`python bench.py --gpus 8`: eight self-launched ranks (gloo here, RCCL on the node) -- the collective sees all eight
+    (`rccl_world`), the weak job gathers 8 x steps tables, the strong job (BASELINE config 4: a FIXED set of micrographs dealt
+    i = rank mod 8) gathers exactly --images of them, ragged shares included"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    for extra, n_img in ((['--steps', '2'], 16), (['--scaling', 'strong', '--images', '21'], 21)):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--dry-run'] + extra,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out['n_gpus'] == 8 and out['rccl_world'] == 8 and out['images_gathered'] == n_img, out
+        assert out['rank_ms_per_step']['max'] >= out['rank_ms_per_step']['min'] > 0
 
 
 def test_launch_local_ranks_propagates_failure():
@@ -187,3 +222,37 @@ def test_sum_to_root_assembles_tile_sharded_volume_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_rank_cpu_sets_follow_the_gpu_numa_nodes(tmp_path):
+    """launch_local_ranks pins rank r to CPUs of GPU r's NUMA node (sysfs: /sys/class/drm/cardN/device/numa_node and the
+    node's cpulist), GPUs of one node sharing it in equal slices; unreadable topology -> equal slices of the allowed CPUs.
+    A rank really starts with that affinity."""
+    import sys
+    from topaz_amd.parallel import cpu_sets_for_ranks, launch_local_ranks
+    root = tmp_path / 'sys'
+    for card, node in enumerate([0, 0, 1, 1]):
+        d = root / 'class' / 'drm' / f'card{card}' / 'device'
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text(f'{node}\n')
+    (root / 'class' / 'drm' / 'card0-DP-1').mkdir()               # a connector entry: not a device
+    for node, cpus in ((0, '0-7,16-23'), (1, '8-15,24-31')):
+        d = root / 'devices' / 'system' / 'node' / f'node{node}'
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cpus + '\n')
+    sets = cpu_sets_for_ranks(4, sysfs=str(root), allowed=range(32))
+    assert sets == [[0, 1, 2, 3, 4, 5, 6, 7], [16, 17, 18, 19, 20, 21, 22, 23], [8, 9, 10, 11, 12, 13, 14, 15],
+                    [24, 25, 26, 27, 28, 29, 30, 31]]
+    # restricted affinity mask of the launcher is respected
+    assert cpu_sets_for_ranks(2, sysfs=str(root), allowed=range(0, 8)) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    # more ranks than GPUs listed, or no topology at all: equal contiguous slices
+    assert cpu_sets_for_ranks(8, sysfs=str(root), allowed=range(16)) == [[2 * i, 2 * i + 1] for i in range(8)]
+    assert cpu_sets_for_ranks(2, sysfs=str(tmp_path / 'nothing'), allowed=range(6)) == [[0, 1, 2], [3, 4, 5]]
+    # numa_node -1 (single-socket hosts report it): fallback as well
+    (root / 'class' / 'drm' / 'card1' / 'device' / 'numa_node').write_text('-1\n')
+    assert cpu_sets_for_ranks(2, sysfs=str(root), allowed=range(4)) == [[0, 1], [2, 3]]
+    # a launched rank runs with the affinity the launcher announced to it
+    code = ('import os, sys\n'
+            'want = sorted(int(c) for c in os.environ["TOPAZ_AMD_RANK_CPUS"].split(","))\n'
+            'sys.exit(0 if sorted(os.sched_getaffinity(0)) == want else 7)\n')
+    assert launch_local_ranks(2, [sys.executable, '-c', code]) == 0

@@ -178,6 +178,68 @@ def test_chained_config4_denoise_score_nms_vs_oracle_chain(gpu_ctx, nets):
     assert np.array_equal(c2, co) and np.array_equal(s2, so)
 
 
+def _sample_windows(n, size, H, W, seed):
+    """n window origins of size^2: the four corners, the four edge midpoints, the rest uniformly at random"""
+    fixed = [(0, 0), (0, W - size), (H - size, 0), (H - size, W - size), (0, W // 2), (H - size, W // 2), (H // 2, 0),
+             (H // 2, W - size)]
+    rs = np.random.RandomState(seed)
+    rest = [(int(rs.randint(0, H - size + 1)), int(rs.randint(0, W - size + 1))) for _ in range(n - len(fixed))]
+    return fixed + rest
+
+
+def test_config4_chain_at_4096_every_patch_and_4096_sampled_logits(gpu_ctx):
+    """BASELINE config 4 at its own size, on the bench's own networks, stage by stage and end to end, ABSOLUTE 1e-4:
+      * denoise (-s 1024 -p 500): EVERY one of the 16 patch centres against the oracle's `_denoise` of that patch's crop
+        (denoise.py:307-322) -- the oracle's denoised micrograph is assembled from them;
+      * score: 4096 logits sampled as 64 windows of 8 x 8 (corners, edges, random) + six 256^2 windows, (a) the device's
+        scorer against the oracle scoring the DEVICE's denoised image (stage parity on identical input), (b) the device
+        chain against the oracle chain (oracle scorer on the oracle's denoised image);
+      * NMS (r = 14, t = -6): the device's pick table equals the C oracle's greedy suppression of the device's score map,
+        bit for bit, all 16.7 M pixels."""
+    from topaz_amd.algorithms import non_maximum_suppression
+    d, sd_d = _bench_unet()
+    m, sd_s = _bench_resnet()
+    H = W = 4096
+    x = np.random.RandomState(1000).randn(H, W).astype(np.float32)
+    den_t = d.denoise_device(torch.from_numpy(x).cuda(), 1024, 500)
+    logits_t = m(den_t[None, None])[0, 0]
+    s, c = non_maximum_suppression(logits_t, 14, threshold=-6.0)
+    den, logits = den_t.cpu().numpy(), logits_t.cpu().numpy()
+    # ---- denoise: all 16 patches
+    tsd = oden.to_torch_sd(sd_d)
+    den_ref = np.empty_like(den)
+    worst_den = 0.0
+    for i in range(0, H, 1024):
+        for j in range(0, W, 1024):
+            si, ei, sj, ej = max(0, i - 500), min(H, i + 1524), max(0, j - 500), min(W, j + 1524)
+            ref = oden.denoise_whole('unet', tsd, torch.from_numpy(x[si:ei, sj:ej].copy()))
+            den_ref[i:i + 1024, j:j + 1024] = ref[i - si:i - si + 1024, j - sj:j - sj + 1024]
+            e = _abs(den[i:i + 1024, j:j + 1024], den_ref[i:i + 1024, j:j + 1024])
+            assert e <= ATOL, (i, j, e)
+            worst_den = max(worst_den, e)
+    # ---- score: sampled windows, stage-wise and end to end
+    p = 35
+    wins = [(y0, x0, 8) for (y0, x0) in _sample_windows(64, 8, H, W, 5)] + [(y0, x0, 256) for (y0, x0) in WINDOWS]
+    worst_stage = worst_chain = 0.0
+    for (y0, x0, size) in wins:
+        ys, xs, ye, xe = max(0, y0 - p), max(0, x0 - p), min(H, y0 + size + p), min(W, x0 + size + p)
+        got = logits[y0:y0 + size, x0:x0 + size]
+        for src, name in ((den, 'stage'), (den_ref, 'chain')):
+            ref = oscoring.score('resnet8', sd_s, src[ys:ye, xs:xe])[y0 - ys:y0 - ys + size, x0 - xs:x0 - xs + size]
+            e = _abs(got, ref)
+            assert e <= ATOL, (name, y0, x0, size, e)
+            if name == 'stage':
+                worst_stage = max(worst_stage, e)
+            else:
+                worst_chain = max(worst_chain, e)
+    # ---- NMS: the whole table against the C oracle on the same map
+    so, co = onms.nms2d(logits, 14, -6.0)
+    assert len(so) > 10000
+    assert np.array_equal(np.asarray(c), co) and np.array_equal(np.asarray(s), so)
+    print(f'config 4 at 4096^2: |den| {worst_den:.2e} over 16 patches; |logit| stage {worst_stage:.2e}, chain {worst_chain:.2e} '
+          f'over {sum(w[2] ** 2 for w in wins)} sampled logits; {len(so)} picks identical')
+
+
 def test_small_magnitude_activations_split_floor(gpu_ctx):
     """The lo half of a split value is an f16 with an absolute floor of 2^-25 (below it the value carries fewer than
     22 bits).  Layer level: activations of magnitude 1e-3 ... 1e-7 through one 2xf16 convolution against float64 --

@@ -52,11 +52,19 @@ def test_prelu_slopes_outside_unit_interval(gpu_ctx):
     assert len(acts) == 3
     x = z['x0']
     for slopes in ((1.7, -0.4, 0.0), (0.3, 2.5, 1.0), (1.0001, 0.999, 3.0)):
+        sd = dict(sd)
         for k, v in zip(acts, slopes):
             sd[k] = np.full_like(np.asarray(sd[k]), v)
+        # slopes > 1 amplify the negative lobe layer after layer: the (linear) head is rescaled so that the logits keep the
+        # range of a real detector (|logit| <= 20) and the tolerance below is the ABSOLUTE 1e-4 of every other test
+        peak = float(np.abs(oscoring.score('conv31', sd, x)).max())
+        if peak > 20:
+            for k in ('classifier.weight', 'classifier.bias'):
+                sd[k] = (np.asarray(sd[k], dtype=np.float64) * (20.0 / peak)).astype(np.float32)
         ref = oscoring.score('conv31', sd, x)
+        assert np.abs(ref).max() <= 20.5
         y = _score(LinearClassifier('conv31', sd), x)
-        assert np.abs(y - ref).max() <= ATOL * max(1.0, float(np.abs(ref).max()) / 20), slopes
+        assert np.abs(y - ref).max() <= ATOL, (slopes, float(np.abs(y - ref).max()))
 
 
 @pytest.mark.parametrize('arch,units', [('resnet8', 64), ('resnet16', 64), ('resnet8', 32)])

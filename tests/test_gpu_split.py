@@ -59,8 +59,11 @@ def test_conv_split(gpu_ctx, case):
     y, ovf = rt.conv_split(x, w.numpy(), b.numpy(), dil=dil, slope=slope)
     assert not ovf
     e_split, e_f32 = _err(y, ref64), _err(ref32, ref64)
+    print(f'conv_split {case}: err vs float64 (scaled by 1 + |ref|): 2xf16 {e_split:.2e}, torch fp32 {e_f32:.2e}')
     assert _err(y, ref32) <= 1e-4
-    assert e_split <= max(4 * e_f32, 2e-6), (e_split, e_f32)    # fp32-level accuracy, not f16-level
+    # against float64 the layer is as accurate as torch's fp32 convolution of the same layer, to within a factor 1.5 (the
+    # bound DESIGN.md 3.1 states; 22-bit operands, fp32 accumulation) -- not merely "not f16-level"
+    assert e_split <= max(1.5 * e_f32, 1e-6), (e_split, e_f32)
 
 
 def test_conv_split_residual_bn(gpu_ctx):
@@ -285,3 +288,45 @@ def test_split_path_is_bitwise_reproducible(gpu_ctx):
     z0 = dn.denoise_device(x, 256, 64).clone()
     for _ in range(2):
         assert torch.equal(z0, dn.denoise_device(x, 256, 64))
+
+
+@pytest.mark.parametrize('wgs', [8, 24])
+@pytest.mark.parametrize('case', [
+    # cin, cout, k, dil, H, W, slope, residual
+    (128, 128, 3, 8, 150, 170, 0.0, True),      # 8 chunks (even): the input buffers keep their parity from tile to tile
+    (128, 128, 3, 4, 120, 200, 0.0, False),     # two steps per stage
+    (64, 64, 3, 2, 90, 260, 0.0, False),        # 4-wave tile, two workgroups per CU
+    (64, 64, 3, 4, 130, 141, 0.25, True),
+    (72, 100, 3, 4, 101, 143, 0.0, False),      # 9 cells: odd number of chunks (parity flips every tile), short last chunk
+    (24, 48, 3, 1, 77, 300, 0.1, False),        # 3 cells -> 2 chunks, second one short
+    (64, 32, 5, 1, 64, 200, 0.1, False),        # 5x5, two steps per stage
+    (96, 96, 3, 1, 60, 333, 0.1, False),
+])
+def test_persistent_workgroups_are_bit_identical(gpu_ctx, case, wgs):
+    """Persistent workgroups (conv_split.h MODE 4): a handful of workgroups walk all tiles of the layer, each fetching the
+    first chunk / weight stage of its next tile during the last chunk of the current one.  The result must not differ by one
+    bit from the one-tile-per-workgroup launch, for even and odd chunk / stage counts (buffer parities), short last chunks,
+    multi-step stages, residual epilogues and images whose last tiles overhang."""
+    from topaz_amd import runtime as rt
+    cin, cout, k, dil, H, W, slope, with_res = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(cin, H, W, generator=g) * 2
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g)
+    Ho, Wo = H - dil * (k - 1), W - dil * (k - 1)
+    res = torch.randn(cout, Ho + 4, Wo + 4, generator=g) if with_res else None
+    kw = dict(dil=dil, slope=slope, res=res, res_crop=2 if with_res else 0)
+    gpu_ctx.set_persist(0)
+    try:
+        y0, ovf0 = rt.conv_split(x, w.numpy(), b.numpy(), **kw)
+        gpu_ctx.set_persist(2, wgs)
+        y1, ovf1 = rt.conv_split(x, w.numpy(), b.numpy(), **kw)
+    finally:
+        gpu_ctx.set_persist(1, 0)
+    ref = F.conv2d(x[None], w, b, dilation=dil)[0]
+    if with_res:
+        ref = ref + res[:, 2:-2, 2:-2]
+    ref = _act(ref, slope)
+    assert not ovf0 and not ovf1
+    assert _err(y0, ref) <= 1e-4
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())

@@ -23,16 +23,16 @@ const SplitStep* make_plan(const SplitArgs& a) {
     return d;
 }
 
-template <class C, int EPI, int ABL>
+template <class C, int EPI, int ABL, int MODE = 0>
 float run(const SplitArgs& a, dim3 grid, int iters) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, ABL, 0>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, ABL, MODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, MODE>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((conv_split_kernel<C, EPI, ABL, MODE>), grid, dim3(C::THREADS), C::LDS_BYTES, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -55,8 +55,8 @@ int bench(const char* name, int cin, int cout, int H) {
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;
     CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
-    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 64));
-    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 64));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 256));
+    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 256));
     // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
     std::vector<uint16_t> h(1 << 21);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x2800 + ((i * 2654435761u) >> 20) % 0x1000) | (uint16_t)(((i * 40503u) >> 7) & 1) << 15;
@@ -79,7 +79,7 @@ int bench(const char* name, int cin, int cout, int H) {
     const double tf = 2.0 * cout * cin * C::K * C::K * (double)Ho * Ho / 1e12;
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
            n_st * a.cog_inner);
-#define RUN(ABL, label) { hipMemset(flag, 0, 64); float ms = run<C, EPI, (ABL) | 2048>(a, grid, 6); unsigned long long c[4]; hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost); \
+#define RUN(ABL, label) { hipMemset(flag, 0, 256); float ms = run<C, EPI, (ABL) | 2048>(a, grid, 6); unsigned long long c[4]; hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost); \
     printf("  %-52s %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", label, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0); }
     if (g_exp) {
         // round-3 experiments on the plan-driven K loop: DMA form, where in the step the DMA is issued, order of fragment 0
@@ -88,9 +88,7 @@ int bench(const char* name, int cin, int cout, int H) {
             printf(" issuer_half = %d\n", ih);
             RUN(0, "baseline (buffer DMA, issued at the top of the step)");
             RUN(65536, "round-2 DMA forms (global_load_lds)");
-            RUN(131072, "fragment 0: MFMAs first, then the A(1) request");
-            RUN(262144, "DMA issued mid-step");
-            RUN(262144 | 131072, "DMA mid-step + fragment 0 MFMAs first");
+            RUN(131072, "fragment 0: A(1) request first (round-2 order)");
             RUN(0, "baseline (again)");
         }
         return 0;
@@ -149,8 +147,8 @@ int quick(const char* name, int cin, int cout, int H) {
     float *in, *w, *out, *res, *zeros, *vec;
     unsigned* flag;
     CHK(hipMalloc(&in, n_in * 4)); CHK(hipMalloc(&w, n_w * 4)); CHK(hipMalloc(&out, n_out * 4)); CHK(hipMalloc(&res, n_out * 4));
-    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 64));
-    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 64));
+    CHK(hipMalloc(&zeros, 256)); CHK(hipMalloc(&vec, (cout + 512) * 4)); CHK(hipMemset(vec, 0, (cout + 512) * 4)); CHK(hipMalloc(&flag, 256));
+    CHK(hipMemset(zeros, 0, 256)); CHK(hipMemset(flag, 0, 256));
     // f16 bit patterns of small normal numbers (0x2xxx..0x3xxx ~ 0.01 .. 1)
     std::vector<uint16_t> h(1 << 21);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint16_t)(0x2800 + ((i * 2654435761u) >> 20) % 0x1000) | (uint16_t)(((i * 40503u) >> 7) & 1) << 15;
@@ -174,11 +172,43 @@ int quick(const char* name, int cin, int cout, int H) {
     printf("%s cin=%d cout=%d out=%d^2 (%.2f TFLOP fp32-equivalent) LDS=%d B, %d steps/tile\n", name, cin, cout, Ho, tf, C::LDS_BYTES,
            n_st * a.cog_inner);
     for (int rep = 0; rep < 3; ++rep) {
-        hipMemset(flag, 0, 64);
+        hipMemset(flag, 0, 256);
         float ms = run<C, EPI, 2048>(a, grid, 10);
-        unsigned long long c[4];
-        hipMemcpy(c, flag, 32, hipMemcpyDeviceToHost);
-        printf("  run %d  %8.3f ms  %6.1f TF/s   clock %.3f GHz\n", rep, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0);
+        unsigned long long c[6];
+        hipMemcpy(c, flag, 48, hipMemcpyDeviceToHost);
+        // cycles per workgroup (11 launches accumulated): whole kernel, prologue (tables + first tile + wait), K loop, epilogue
+        const double nwg = 11.0 * grid.x * grid.y * grid.z;
+        printf("  run %d  %8.3f ms  %6.1f TF/s   clock %.3f GHz   cycles/tile: total %.0f = prologue %.0f + K loop %.0f (%.0f / step) + epilogue %.0f\n",
+               rep, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0, c[1] / nwg, c[3] / nwg, c[4] / nwg,
+               c[4] / nwg / (n_st * a.cog_inner), (c[1] - c[3] - c[4]) / nwg);
+    }
+    for (int ih = 0; ih < (C::ISSUER_HALF ? 2 : 1); ++ih) {
+        // where a step's cycles go (ABL 4096): per wave, averaged over all steps of all tiles
+        SplitArgs t = a;
+        t.issuer_half = ih;
+        hipMemset(flag, 0, 256);
+        float ms = run<C, EPI, 2048 | 4096>(t, grid, 10);
+        unsigned long long c[16];
+        hipMemcpy(c, flag, 128, hipMemcpyDeviceToHost);
+        const double nst = 11.0 * grid.x * grid.y * grid.z * n_st * a.cog_inner;
+        printf("  step timeline (issuer_half %d, %.3f ms): wave 0: dma %.0f | frags %.0f | drain+barrier %.0f | last frag %.0f   wave %d: dma %.0f | frags %.0f | drain+barrier %.0f | last frag %.0f\n",
+               ih, ms, c[5] / nst, c[6] / nst, c[7] / nst, c[8] / nst, C::WAVES / 2, c[9] / nst, c[10] / nst, c[11] / nst, c[12] / nst);
+    }
+    if constexpr (EPI != EPI_HEAD) {
+        // persistent workgroups (MODE 4): CUs x workgroups-per-CU of them walk the tiles, each prefetching its next tile
+        SplitArgs p = a;
+        p.n_tiles = (int)(grid.x * grid.y * grid.z);
+        const dim3 pgrid(256 * C::WGS_PER_CU, 1, 1);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemset(flag, 0, 256);
+            float ms = run<C, EPI, 2048, 4>(p, pgrid, 10);
+            unsigned long long c[6];
+            hipMemcpy(c, flag, 48, hipMemcpyDeviceToHost);
+            const double nwg = 11.0 * p.n_tiles;
+            printf("  persistent run %d  %8.3f ms  %6.1f TF/s   clock %.3f GHz   cycles/tile: total %.0f = prologue %.0f + K loop %.0f (%.0f / step) + epilogue %.0f\n",
+                   rep, ms, tf / (ms * 1e-3), c[2] ? 0.1 * (double)c[1] / (double)c[2] : 0.0, c[1] / nwg, c[3] / nwg, c[4] / nwg,
+                   c[4] / nwg / n_st, (c[1] - c[3] - c[4]) / nwg);
+        }
     }
     hipFree(in); hipFree(w); hipFree(out); hipFree(res); hipFree(zeros); hipFree(vec); hipFree(flag);
     return 0;

@@ -77,6 +77,7 @@ _SIGNATURES = {
     'tpz_ctx_set_exact': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_lanes': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_roi': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_persist': (C.c_int, [_P, C.c_int, C.c_int]),
     'tpz_model_split_stats': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'tpz_conv_split_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_int)]),
@@ -85,6 +86,7 @@ _SIGNATURES = {
     'tpz_prof_get_dominant': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     'tpz_prof_get_kernel': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     'tpz_prof_get': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    'tpz_prof_get_kernel_bytes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -88,6 +88,7 @@ struct SplitArgs {
     int n_chunks;             // chunks of CC (virtual) cells
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
+    int n_tiles;              // persistent launches (MODE 4): tiles_x * tiles_y * grid-z slices, walked by gridDim.x workgroups
     int xcd_swizzle;
     // output WINDOW of the launch, in its own lattice coordinates: the tiles cover [wy0, wy1) x [wx0, wx1) only and nothing
     // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
@@ -122,6 +123,8 @@ enum : uint32_t {
     SPLIT_DMA_NCELL_SHIFT = 9,        // bits 9-11: the chunk's cells that exist when fewer than CC (0 = all CC)
     SPLIT_DMA_SWITCH = 1u << 12,      // first fetch from the second source: its offset table replaces the first one's
     SPLIT_DMA_SRC2 = 1u << 13,        // 2-D: the chunk comes from `in2`
+    SPLIT_DMA_NEXT = 1u << 14,        // the fetch is chunk 0 of the workgroup's NEXT tile (persistent kernels; others skip it);
+                                      // with SPLIT_DMA_SWITCH: its first round -- the offset table becomes the next tile's
     SPLIT_DMA_ANY = 1u << 31,
 };
 
@@ -250,6 +253,7 @@ void split_make_plan(const SplitPlanKey& k, std::vector<SplitStep>& out) {
     };
     out.assign((size_t)n_stages + 1, SplitStep{});
     fetch(out[0], 0, (1u << C::NR) - 1, false);
+    unsigned next_rounds = 0;
     for (int s = 0; s < n_stages; ++s) {
         SplitStep& e = out[(size_t)s + 1];
         for (int l4 = 0; l4 < 4; ++l4) {
@@ -299,10 +303,44 @@ void split_make_plan(const SplitPlanKey& k, std::vector<SplitStep>& out) {
             r0 = s - ch * C::NSTEP;
             rstride = C::NSTEP;
         }
-        if (pf >= k.n_chunks || r0 >= C::NR) continue;
-        unsigned rmask = 0;
-        for (int r = r0; r < C::NR; r += rstride) rmask |= 1u << r;
-        fetch(e, pf, rmask, r0 == 0 && pf == chunks1);
+        if (pf < k.n_chunks) {
+            if (r0 >= C::NR) continue;
+            unsigned rmask = 0;
+            for (int r = r0; r < C::NR; r += rstride) rmask |= 1u << r;
+            fetch(e, pf, rmask, r0 == 0 && pf == chunks1);
+        } else if (pf == k.n_chunks && !folded && !vol && !k.has_in2) {
+            // the window of the last chunk: persistent workgroups fetch chunk 0 of their NEXT tile here (same schedule as any
+            // other chunk, into the buffer the chunk numbering -- continued across tiles -- gives it)
+            if (C::CONT) {
+                const int ws = pf >= 2 ? (C::Q * (pf - 1) - 1) / 4 + 1 : 0;
+                const int we = n_stages - 1;                      // (a short last chunk ends early)
+                const int gs = (ws + C::SPS - 1) / C::SPS, ge = (we + 1) / C::SPS - 1;
+                if (stage < gs || stage > ge) continue;
+                r0 = stage - gs;
+                rstride = ge - gs + 1;
+            }
+            if (r0 >= C::NR) continue;
+            unsigned rmask = 0;
+            for (int r = r0; r < C::NR; r += rstride) rmask |= 1u << r;
+            fetch(e, 0, rmask, r0 == 0);
+            e.dma |= SPLIT_DMA_NEXT;
+            if (k.n_chunks & 1) e.dma |= SPLIT_DMA_BUF;           // chunk n_chunks of the continued numbering
+            next_rounds |= rmask;
+        }
+    }
+    // entry 0 says whether the plan holds a complete next-tile fetch (the library launches the persistent kernel only then)
+    if (next_rounds == (1u << C::NR) - 1u) out[0].dma |= SPLIT_DMA_NEXT;
+    // second copy for tiles that start in the other input buffer (persistent workgroups, odd number of chunks per tile)
+    const size_t n = out.size();
+    out.resize(2 * n);
+    for (size_t i = 0; i < n; ++i) {
+        SplitStep e = out[i];
+        for (int l4 = 0; l4 < 4; ++l4) {
+            const int off = e.bofs[l4] * 16;
+            e.bofs[l4] = (uint16_t)((off >= C::IN_BUF ? off - C::IN_BUF : off + C::IN_BUF) / 16);
+        }
+        if (e.dma & SPLIT_DMA_ANY) e.dma ^= SPLIT_DMA_BUF;
+        out[n + i] = e;
     }
 }
 
@@ -328,13 +366,30 @@ template <class C, int EPI, int ABL = 0, int MODE = 3>
 __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     constexpr bool HAS2 = (MODE & 1) != 0, VOLM = (MODE & 2) != 0;
+    // MODE bit 2: PERSISTENT workgroups.  The grid is a few workgroups per CU; each walks its share of the tiles (XCD-aware
+    // order) and, during the last chunk of a tile's K loop, fetches the first chunk and the first weight stage of ITS NEXT tile
+    // (the plan's SPLIT_DMA_NEXT entries): the table computation, the first fetch and its full memory latency -- 6 - 9 k cycles
+    // per tile, 4 % (128-channel 3x3 tiles) to 20 % (48 channels) of a tile's time, profiles/r03_phase_breakdown.txt -- leave
+    // the critical path.  Plain single-source 2-D layers without the fused head only (MODE 4).
+    constexpr bool PERSIST = (MODE & 4) != 0;
+    static_assert(!PERSIST || (MODE == 4 && EPI != EPI_HEAD), "persistent tiles: plain single-source layers");
     const uint4* const in2 = HAS2 ? a.in2 : nullptr;
     const int fold_cells = HAS2 ? a.fold_cells : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned* lds_tab = reinterpret_cast<unsigned*>(lds + C::OFF_TAB);
 
     const int tid = threadIdx.x;
-    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    unsigned long long probe_c0 = 0, probe_r0 = 0, probe_pro = 0, probe_loop = 0;     // (+ phase breakdown: prologue / K loop / epilogue)
+    // ABL 4096 (with 2048): where a step's cycles go, per wave -- DMA code | channel fragments 0 .. MW-2 | DMA drain + barrier |
+    // last fragment + next step's first requests; reported for wave 0 and wave WAVES/2 (the two waves of one SIMD)
+    unsigned long long seg[4] = {0, 0, 0, 0}, seg_t = 0;
+    auto seg_mark = [&](int i) {
+        if constexpr ((ABL & 4096) != 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (i >= 0) seg[i] += t - seg_t;
+            seg_t = t;
+        }
+    };
     if constexpr ((ABL & 2048) != 0) {
         probe_c0 = __builtin_readcyclecounter();
         probe_r0 = __builtin_amdgcn_s_memrealtime();
@@ -343,29 +398,53 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // XCD-aware tile order (see conv_mfma.h)
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (a.xcd_swizzle) {
-        const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
-        const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
-        const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-        bx = (int)(wgid % gridDim.x);
-        by = (int)(wgid / gridDim.x);
+    // ---- tile geometry.  One tile per workgroup (XCD-aware order within a grid-z slice, see conv_mfma.h) or, PERSIST, a
+    // sequence of tiles: linear tile index L = (z * tiles_y + by) * tiles_x + bx; the tiles are dealt to the XCDs in eight
+    // contiguous runs (block b runs on XCD b % 8: neighbouring tiles share their halo in that XCD's L2) and within a run
+    // round-robin to the XCD's workgroups.
+    int y0, x0, cogz, oz, pad_x, pad_y, pad_z, oox, ooy, ooz, phase, ybase, xbase;
+    auto set_tile = [&](int bx, int by, int bz) {
+        y0 = a.wy0 + (by / D) * (C::TH * D) + (by % D);
+        x0 = a.wx0 + bx * C::TW;
+        cogz = bz % a.ncz;
+        oz = bz / a.ncz;                                     // output plane of the launch lattice (0 in 2-D)
+        pad_x = a.pad_x; pad_y = a.pad_y; pad_z = a.pad_z; oox = a.oox; ooy = a.ooy; ooz = a.ooz; phase = 0;
+        if (a.nphase > 0) {
+            phase = oz % a.nphase;
+            oz /= a.nphase;
+            oox = phase & 1; ooy = (phase >> 1) & 1; ooz = (phase >> 2) & 1;
+            pad_x = (a.phase_k / 2 - oox + 1) / 2;
+            pad_y = (a.phase_k / 2 - ooy + 1) / 2;
+            pad_z = (a.phase_k / 2 - ooz + 1) / 2;
+        }
+        ybase = y0 - pad_y; xbase = x0 - pad_x;
+    };
+    auto set_tile_linear = [&](unsigned L) {
+        const unsigned txy = (unsigned)(a.tiles_x * a.tiles_y);
+        const unsigned bz = L / txy, rem = L - bz * txy, by = rem / (unsigned)a.tiles_x;
+        set_tile((int)(rem - by * (unsigned)a.tiles_x), (int)by, (int)bz);
+    };
+    unsigned tile_L = 0, tile_end = 0, tile_stride = 1;       // PERSIST: this workgroup's tiles L, L + stride, ... < end
+    if constexpr (PERSIST) {
+        const unsigned nt = (unsigned)a.n_tiles;
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, q = nt / 8, r = nt % 8;
+        const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_end = start + q + (xcd < r ? 1u : 0u);
+        tile_stride = gridDim.x >> 3;
+        tile_L = start + j;
+        if (tile_L >= tile_end) return;                       // (more workgroups than tiles in this XCD's run)
+        set_tile_linear(tile_L);
+    } else {
+        int bx = blockIdx.x, by = blockIdx.y;
+        if (a.xcd_swizzle) {
+            const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+            const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+            bx = (int)(wgid % gridDim.x);
+            by = (int)(wgid / gridDim.x);
+        }
+        set_tile(bx, by, (int)blockIdx.z);
     }
-    const int y0 = a.wy0 + (by / D) * (C::TH * D) + (by % D);
-    const int x0 = a.wx0 + bx * C::TW;
-    const int cogz = (int)blockIdx.z % a.ncz;
-    int oz = (int)blockIdx.z / a.ncz;                        // output plane of the launch lattice (0 in 2-D)
-    int pad_x = a.pad_x, pad_y = a.pad_y, pad_z = a.pad_z, oox = a.oox, ooy = a.ooy, ooz = a.ooz, phase = 0;
-    if (a.nphase > 0) {
-        phase = oz % a.nphase;
-        oz /= a.nphase;
-        oox = phase & 1; ooy = (phase >> 1) & 1; ooz = (phase >> 2) & 1;
-        pad_x = (a.phase_k / 2 - oox + 1) / 2;
-        pad_y = (a.phase_k / 2 - ooy + 1) / 2;
-        pad_z = (a.phase_k / 2 - ooz + 1) / 2;
-    }
-    const int ybase = y0 - pad_y, xbase = x0 - pad_x;
     const bool vol = VOLM && (a.KZ > 1 || a.Din > 1);        // plane-stacked 3-D addressing
 
     // marks a cell outside the image / past the last channel.  16-byte aligned: as the offset of a buffer load all four of its
@@ -379,7 +458,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const bool ups = (a.H1 != a.Hin) || (a.W1 != a.Win);
     // (tid and the sizes nearest_src() divides are passed in: the co-group loop hands over opaque copies, so that nothing of this prologue is
     // hoisted out of that loop and kept in registers across the K loop)
-    auto compute_offsets = [&](bool second, int tid, int H1, int W1, int Hup, int Wup) {
+    auto compute_offsets = [&](bool second, int tid, int H1, int W1, int Hup, int Wup, int ybase, int xbase) {
         const bool fold2 = second && fold_cells > 0;       // the folded source has its own size and origin
         const int Hs = fold2 ? a.in2_H : second ? a.Hin : H1, Ws = fold2 ? a.in2_W : second ? a.Win : W1;
         const int Hv = fold2 ? a.in2_H : a.Hin, Wv = fold2 ? a.in2_W : a.Win;
@@ -410,7 +489,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     // the plan is read through the scalar cache: one s_load_dwordx8 per step, a step ahead of its use
     typedef uint32_t StepW __attribute__((ext_vector_type(8)));
     typedef const __attribute__((address_space(4))) StepW* plan_ptr_t;
-    const plan_ptr_t plan = (plan_ptr_t)a.plan;
+    const plan_ptr_t plan0 = (plan_ptr_t)a.plan;
 
     // One LDS-DMA instruction moves 16 bytes per lane, 1 KiB per wave.  Two ways to issue it:
     //  * per-lane 64-bit source address through the builtin (glds16): lanes whose cell lies outside the image (or past the last
@@ -565,10 +644,30 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     const int n_stages = n_stages_a + (folded ? fold_cells / C::CC : 0);    // + one step per folded chunk
     const size_t w_cog_bytes = (size_t)n_stages * C::W_STEP_BYTES;
 
+    // PERSIST: parities of the input / weight buffers at the start of the current tile (chunks and stages are numbered on across
+    // tiles: a tile with an odd number of them leaves the next one starting in the other buffer; the plan has a copy for either
+    // input parity), and whether the current tile's first chunk + first weight stage were already fetched by its predecessor
+    const int n_wstages = (n_stages + C::SPS - 1) / C::SPS;
+    int par_in = 0, par_w = 0;
+    bool prefetched = false;
+    auto wcog_of = [&](int phase, int cog) {
+        return reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)phase * a.w_phase_bytes + (size_t)cog * w_cog_bytes;
+    };
+    for (;;) {                                  // tiles of this workgroup (exactly one when !PERSIST)
+    const bool has_next = PERSIST && tile_L + tile_stride < tile_end;
+    int n_ybase = 0, n_xbase = 0, n_phase = 0, n_cog = 0;     // origin, phase and co-group of the next tile
+    if (PERSIST && has_next) {
+        const int sy0 = y0, sx0 = x0, scogz = cogz, soz = oz, spx = pad_x, spy = pad_y, spz = pad_z, sox = oox, soy = ooy,
+                  soz2 = ooz, sph = phase, syb = ybase, sxb = xbase;
+        set_tile_linear(tile_L + tile_stride);
+        n_ybase = ybase; n_xbase = xbase; n_phase = phase; n_cog = cogz;
+        y0 = sy0; x0 = sx0; cogz = scogz; oz = soz; pad_x = spx; pad_y = spy; pad_z = spz; oox = sox; ooy = soy; ooz = soz2;
+        phase = sph; ybase = syb; xbase = sxb;
+    }
+    const plan_ptr_t plan = plan0 + (PERSIST && par_in ? n_stages + 1 : 0);
     for (int cg = 0; cg < a.cog_inner; ++cg) {
         const int cog = cogz * a.cog_inner + cg;
-        const unsigned char* wcog = reinterpret_cast<const unsigned char*>(a.wpk) + (size_t)phase * a.w_phase_bytes +
-                                    (size_t)cog * w_cog_bytes;
+        const unsigned char* wcog = wcog_of(phase, cog);
         const float* wscale = a.wscale + (size_t)phase * a.ws_phase_stride;
         f32x4 acc[MW][NW];
 #pragma unroll
@@ -576,6 +675,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        unsigned long long probe_t0 = 0;
+        if constexpr ((ABL & 2048) != 0) probe_t0 = (cg == 0 && !prefetched) ? probe_c0 : __builtin_readcyclecounter();
         __syncthreads();                       // previous co-group done with the buffers
         // the prologue of a co-group works from opaque copies of the thread id and the source size: its lane-dependent
         // values are then computed here and die here, instead of being hoisted out of this loop and spilled across the
@@ -583,13 +684,15 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         int tid_p = tid, H1_p = a.H1, W1_p = a.W1, Hup_p = a.Hin, Wup_p = a.Win;
         asm volatile("" : "+v"(tid_p), "+s"(H1_p), "+s"(W1_p), "+s"(Hup_p), "+s"(Wup_p));
         const int wave_p = __builtin_amdgcn_readfirstlane(tid_p >> 6), l4_p = (tid_p & 63) >> 4;
-        const StepW P0 = plan[0];              // the fetch of chunk 0
         StepW P = plan[1];                     // step 0
-        compute_offsets((P0[2] & SPLIT_DMA_SRC2) != 0, tid_p, H1_p, W1_p, Hup_p, Wup_p);
-        fetch(P0, (1u << C::NR) - 1u, tid_p, wave_p);
-        issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid_p, wave_p);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(PERSIST && prefetched)) {
+            const StepW P0 = plan0[0];         // the fetch of chunk 0
+            compute_offsets((P0[2] & SPLIT_DMA_SRC2) != 0, tid_p, H1_p, W1_p, Hup_p, Wup_p, ybase, xbase);
+            fetch(P0, (1u << C::NR) - 1u, tid_p, wave_p);
+            issue_weights(wcog, 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, 0, tid_p, wave_p);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 
         // The first fragments of a step -- all its B fragments (hi, lo) and A(0) -- are loop-carried registers: they are
         // refreshed IN PLACE for step s + 1 during the last channel fragment of step s, each right after the last MFMA
@@ -604,11 +707,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 bh[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n));
                 bo[n] = *reinterpret_cast<const f16x8*>(bl + b_off(n) + C::PLANE_BYTES);
             }
-            const unsigned a_lane_p = (unsigned)(C::OFF_W + (tid_p & 63) * 16);
+            const unsigned a_lane_p = (unsigned)(C::OFF_W + (tid_p & 63) * 16 + (PERSIST ? par_w * C::W_STAGE_BYTES : 0));
             ah[0] = *reinterpret_cast<const f16x8*>(lds + a_lane_p);
             ao[0] = *reinterpret_cast<const f16x8*>(lds + a_lane_p + MW * 1024);
         }
 
+        unsigned long long probe_t1 = 0;
+        if constexpr ((ABL & 2048) != 0) probe_t1 = __builtin_readcyclecounter();
 #pragma unroll 1
         for (int s = 0; s < n_stages; ++s) {
             const int stage = s / C::SPS, sub = s - stage * C::SPS;      // (SPS = 1: stage = s, sub = 0)
@@ -628,13 +733,22 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
                         const int left = n_stages - (stage + 1) * C::SPS;            // steps of the next stage
-                        if (left > 0) issue_weights(wcog, stage + 1, (left < C::SPS ? left : C::SPS) * C::W_STEP_BYTES, (stage + 1) & 1, vt, vw);
+                        const int wb = PERSIST ? (stage + 1 + par_w) & 1 : (stage + 1) & 1;
+                        if (left > 0) issue_weights(wcog, stage + 1, (left < C::SPS ? left : C::SPS) * C::W_STEP_BYTES, wb, vt, vw);
+                        else if (PERSIST && has_next)      // the last stage: the first stage of the next tile takes its place
+                            issue_weights(wcog_of(n_phase, n_cog), 0, (n_stages < C::SPS ? n_stages : C::SPS) * C::W_STEP_BYTES, wb, vt, vw);
                     }
                 }
-                if (!(ABL & 256) && (P[2] & SPLIT_DMA_ANY)) {
+                const bool next_fetch = (P[2] & SPLIT_DMA_NEXT) != 0;      // chunk 0 of the NEXT tile (persistent workgroups only)
+                if (!(ABL & 256) && (P[2] & SPLIT_DMA_ANY) && (!next_fetch || (PERSIST && has_next))) {
                     if (HAS2 && (P[2] & SPLIT_DMA_SWITCH)) {
-                        compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win);         // switching to the second source
+                        compute_offsets(true, tid, a.H1, a.W1, a.Hin, a.Win, ybase, xbase);         // switching to the second source
                         if (iss) __syncthreads();                                     // the issuing waves read other threads' entries
+                    }
+                    if (PERSIST && next_fetch && (P[2] & SPLIT_DMA_SWITCH)) {
+                        // the current tile's last fetch was issued in an earlier step: the table now becomes the next tile's
+                        compute_offsets(false, tid, a.H1, a.W1, a.Hin, a.Win, n_ybase, n_xbase);
+                        if (iss) __syncthreads();
                     }
                     for (int rep = 0; rep < reps; ++rep) {
                         const int vw = iss ? wave - 4 * (1 - rep) : wave, vt = iss ? tid - 256 * (1 - rep) : tid;
@@ -643,44 +757,30 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 }
             }
             };
-            // where in the step it is issued: at the top (every wave issues its pieces before its first MFMA), or, DMA_AT > 0,
-            // between the MFMAs of channel fragments DMA_AT - 1 and DMA_AT
-            constexpr int DMA_AT = ((ABL & 262144) && MW >= 2) ? (MW >= 4 ? MW / 2 : 1) : 0;
-            constexpr bool MFMA_FIRST = (ABL & 131072) != 0;       // fragment 0: first NW MFMAs, then the A(1) request
-            if constexpr (DMA_AT == 0) step_dma();
+            // (issued at the top of the step.  Issuing it between the MFMAs of the middle channel fragments instead was measured:
+            // +-0 on the narrow tiles, -8 % with issuer_half -- profiles/r03_kloop_experiments.txt)
+            seg_mark(s == 0 ? -1 : 3);
+            step_dma();
+            seg_mark(0);
+            // Fragment 0 issues its first NW MFMAs BEFORE the request for A(1): the wait in front of the step's first MFMA is an
+            // lgkmcnt(0) whatever is in flight (the plan's scalar load returns out of order), so the A(1) request would be
+            // waited for there as well (+1.5 % on the fused-head kernel; ABL 131072 = the old order)
+            constexpr bool MFMA_FIRST = (ABL & 131072) == 0;
             // ---- the step's MFMAs, register-pipelined across the step barrier:
             //   channel fragments 0 .. MW-2 (A(m + 1) requested one fragment ahead), then the DMA drain + barrier, then the
             //   MFMAs of the last channel fragment -- which need registers only -- interleaved with the requests for the
             //   B fragments and A(0) of step s + 1.  The matrix core is not left idle for an LDS round trip after every
             //   barrier (150 - 250 cycles of a step of 768 (MT = 64) ... 3072 (MT = 128, 8 waves) cycles).
             //   MFMA order within a channel fragment: ah*bo, ah*bh, ao*bh -- the lo halves of B are released first.
-            const unsigned char* al = lds + a_lane + (stage & 1) * C::W_STAGE_BYTES + sub * C::W_STEP_BYTES;
+            const int wpar = PERSIST ? par_w : 0;
+            const unsigned char* al = lds + a_lane + ((stage + wpar) & 1) * C::W_STAGE_BYTES + sub * C::W_STEP_BYTES;
             const int stage_n = (s + 1) / C::SPS;
-            const unsigned char* al_next = lds + a_lane + (stage_n & 1) * C::W_STAGE_BYTES + (s + 1 - stage_n * C::SPS) * C::W_STEP_BYTES;
+            const unsigned char* al_next = lds + a_lane + ((stage_n + wpar) & 1) * C::W_STAGE_BYTES + (s + 1 - stage_n * C::SPS) * C::W_STEP_BYTES;
             const unsigned char* bl_next = nullptr;
             constexpr bool A0_EARLY = (MW % 2 == 0);          // slot 0 of ah / ao is free during the last fragment (slot 1)
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const int t = m & 1;
-                if (DMA_AT > 0 && m == DMA_AT && MW > 1) {
-                    // pin the fragments so far, then the step's DMA between two scheduling barriers
-                    if constexpr (!(ABL & 16) && !(ABL & 8)) {
-#pragma unroll
-                        for (int mm = 0; mm < DMA_AT; ++mm) {
-                            if (mm == 0 && MFMA_FIRST) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, NW, 2);
-                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NW, 2);
-                            } else {
-                                __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);         // A(mm + 1)
-                                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NW, 2);    // MFMAs of mm
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    step_dma();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (m + 1 < MW) {
                     if constexpr (!(ABL & 8)) {
                         ah[t ^ 1] = *reinterpret_cast<const f16x8*>(al + (m + 1) * 1024);
@@ -695,7 +795,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     // LDS latencies per step)
                     if constexpr (!(ABL & 16) && !(ABL & 8)) {
 #pragma unroll
-                        for (int mm = (DMA_AT < MW ? DMA_AT : 0); mm + 1 < MW; ++mm) {
+                        for (int mm = 0; mm + 1 < MW; ++mm) {
                             if (mm == 0 && MFMA_FIRST) {
                                 __builtin_amdgcn_sched_group_barrier(0x008, NW, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -707,11 +807,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    seg_mark(1);
                     if (C::SPS == 1 || stage_end) {
                         if constexpr (!(ABL & 16384))
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA piece this wave issued in this stage has landed
                         if constexpr (!(ABL & 4)) __syncthreads();
                     }
+                    seg_mark(2);
                     bl_next = b_frag_base(Pn, l4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -761,6 +863,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 }
             }
             P = Pn;
+        }
+        if constexpr ((ABL & 2048) != 0) {
+            probe_loop += __builtin_readcyclecounter() - probe_t1;
+            probe_pro += probe_t1 - probe_t0;
         }
 
         // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store.
@@ -926,12 +1032,28 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         }
         big = big || bigacc[0] >= 0x7c00 || bigacc[1] >= 0x7c00;
     }  // co-group loop
+    if (!(PERSIST && has_next)) break;
+    // ---- the workgroup's next tile: its first chunk and weight stage are in the LDS already
+    tile_L += tile_stride;
+    set_tile_linear(tile_L);
+    par_in ^= a.n_chunks & 1;
+    par_w ^= n_wstages & 1;
+    prefetched = true;
+    }  // tile loop
 
     if constexpr ((ABL & 2048) != 0) {
         if (threadIdx.x == 0) {
             unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.flag) + 1;
             atomicAdd(ctr, __builtin_readcyclecounter() - probe_c0);
             atomicAdd(ctr + 1, __builtin_amdgcn_s_memrealtime() - probe_r0);
+            atomicAdd(ctr + 2, probe_pro);
+            atomicAdd(ctr + 3, probe_loop);
+        }
+        if constexpr ((ABL & 4096) != 0) {
+            if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == C::WAVES / 2)) {
+                unsigned long long* ctr = reinterpret_cast<unsigned long long*>(a.flag) + 5 + (wave == 0 ? 0 : 4);
+                for (int i = 0; i < 4; ++i) atomicAdd(ctr + i, seg[i]);
+            }
         }
     }
     if constexpr (EPI == EPI_HEAD) {

@@ -22,8 +22,9 @@ struct SplitKernelInfo {
 void register_split(const SplitKernelInfo& info);
 const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
-// two instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code) and the general one
-// (second source and / or plane-stacked 3-D)
+// three instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
+// persistent workgroups that prefetch their next tile (MODE 4; a.n_tiles > 0 selects it, the grid is then (workgroups, 1, 1);
+// not for the fused head) and the general one (second source and / or plane-stacked 3-D)
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
@@ -33,11 +34,26 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if constexpr (EPI != EPI_HEAD)
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (!a.in2 && a.KZ <= 1 && a.Din <= 1) hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    const bool plain = !a.in2 && a.KZ <= 1 && a.Din <= 1;
+    if (a.n_tiles > 0) {
+        if constexpr (EPI != EPI_HEAD) {
+            if (!plain) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 4>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (plain) {
+        hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ static const bool g_no_issuer = getenv("TPZ_NO_ISSUER") != nullptr;
 static const bool g_no_lanes = getenv("TPZ_NO_LANES") != nullptr;      // patches / tiles of an image on one stream only
 // TPZ_NO_ROI=1: every layer of a patch computes its whole tensor (A/B switch; see need_regions)
 static const bool g_no_roi = getenv("TPZ_NO_ROI") != nullptr;
+static const bool g_persist = getenv("TPZ_NO_PERSIST") == nullptr;      // persistent workgroups for the large plain conv_split launches
 
 #ifndef TPZ_N_LANES
 #define TPZ_N_LANES 2
@@ -71,16 +72,17 @@ enum { NMS_BATCH = 4, NMS_VER = 5, NMS_SNAP = 9, NMS_PICKS = 15, NMS_COUNTERS = 
 struct ProfRec {
     int cls;
     hipEvent_t e0, e1;
-    double flops;
-    const void* key;      // identity of the kernel instantiation (its registry name), nullptr for the rest
+    double flops, bytes;  // algorithmic FLOP and HBM bytes of the launch (bytes: read inputs + weights once, write outputs once)
+    const void* key;      // identity of the kernel instantiation (its registry name / a static label), nullptr for the rest
 };
 struct ProfAcc {
-    double ms = 0, flops = 0;
+    double ms = 0, flops = 0, bytes = 0;
     long long n = 0;
 };
 
 struct tpz_ctx {
     int device = 0;
+    int n_cus = 256;              // compute units (persistent grids are sized from it)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -109,6 +111,8 @@ struct tpz_ctx {
     bool lanes_on = false;
     bool lanes_enabled = !g_no_lanes;         // tpz_ctx_set_lanes
     bool roi_enabled = !g_no_roi;             // tpz_ctx_set_roi: patches compute only what their kept centre depends on
+    int persist_mode = g_persist ? 1 : 0;     // tpz_ctx_set_persist: 0 never, 1 large launches (default), 2 every eligible launch
+    int persist_wgs = 0;                      // ... workgroups of a persistent grid (0: CUs x workgroups per CU)
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
@@ -119,7 +123,13 @@ struct tpz_ctx {
     bool exact = g_exact_fp32;    // fp32 kernels only
     // K-loop schedules of the 2xf16 kernels (conv_split.h SplitStep), built on first use per (kernel, layer shape) and kept
     // on the device for the life of the ctx: (kernel, key) -> device table
-    std::vector<std::pair<std::pair<const SplitKernelInfo*, SplitPlanKey>, SplitStep*>> split_plans;
+    struct SplitPlan {
+        const SplitKernelInfo* ks;
+        SplitPlanKey key;
+        SplitStep* d;
+        bool next_ok;             // holds a complete next-tile fetch: the persistent kernel may run this layer
+    };
+    std::vector<SplitPlan> split_plans;
     // profiling
     int prof = 0;                 // 0 off, 1 every launch, 2 conv launches of >= 20 GFLOP only (cheap enough for timed runs)
     bool prof_open = false;
@@ -233,7 +243,7 @@ static int lanes_end(tpz_ctx* ctx) {
 }
 
 // ---- profiling helpers
-static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nullptr) {
+static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nullptr, double bytes = 0) {
     ctx->prof_open = false;
     if (!ctx->prof) return;
     if (ctx->prof == 2 && (cls != 0 || flops < 2e10)) return;
@@ -241,6 +251,7 @@ static void prof_begin(tpz_ctx* ctx, int cls, double flops, const void* key = nu
     ProfRec r;
     r.cls = cls;
     r.flops = flops;
+    r.bytes = bytes;
     r.key = key;
     auto get = [&]() {
         hipEvent_t e;
@@ -272,7 +283,7 @@ static void prof_flush(tpz_ctx* ctx) {
             for (auto& kv : ctx->per_kernel)
                 if (kv.first == r.key) a = &kv.second;
             if (!a) { ctx->per_kernel.push_back({r.key, ProfAcc()}); a = &ctx->per_kernel.back().second; }
-            a->ms += ms; a->flops += r.flops; a->n += 1;
+            a->ms += ms; a->flops += r.flops; a->bytes += r.bytes; a->n += 1;
         }
         ctx->free_events.push_back(r.e0);
         ctx->free_events.push_back(r.e1);
@@ -1180,19 +1191,20 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
 
 // the K-loop schedule of this launch (SplitArgs::plan): tile-invariant, so one table per (kernel, cells, sources) serves every
 // launch of the layer; the first launch builds and uploads it (a blocking copy, once)
-static const SplitStep* split_plan(tpz_ctx* ctx, const SplitKernelInfo& ks, const SplitArgs& a) {
+static const SplitStep* split_plan(tpz_ctx* ctx, const SplitKernelInfo& ks, const SplitArgs& a, bool* next_ok) {
     SplitPlanKey k;
     memset(&k, 0, sizeof k);
     k.cells_in = a.cells_in; k.cells_in1 = a.cells_in1; k.n_chunks = a.n_chunks; k.has_in2 = a.in2 != nullptr;
     k.vol = (a.KZ > 1 || a.Din > 1) ? 1 : 0; k.KZ = a.KZ; k.fold_cells = a.fold_cells; k.fold_tap = a.fold_tap;
     for (auto& e : ctx->split_plans)
-        if (e.first.first == &ks && memcmp(&e.first.second, &k, sizeof k) == 0) return e.second;
+        if (e.ks == &ks && memcmp(&e.key, &k, sizeof k) == 0) { *next_ok = e.next_ok; return e.d; }
     std::vector<SplitStep> h;
     ks.make_plan(k, h);
+    *next_ok = (h[0].dma & SPLIT_DMA_NEXT) != 0;
     SplitStep* d = nullptr;
     if (hipMalloc(&d, h.size() * sizeof(SplitStep)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, h.data(), h.size() * sizeof(SplitStep), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    ctx->split_plans.push_back({{&ks, k}, d});
+    ctx->split_plans.push_back({&ks, k, d, *next_ok});
     return d;
 }
 
@@ -1219,9 +1231,41 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32) - 16)
         return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
     dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
-    a.plan = split_plan(ctx, ks, a);
+    bool next_ok = false;
+    a.plan = split_plan(ctx, ks, a, &next_ok);
     if (!a.plan) return fail(ctx, "out of device memory (K-loop plan)");
-    prof_begin(ctx, 0, flops, ks.name);
+    // Persistent workgroups (conv_split.h MODE 4): a few per CU, each walking its share of the tiles and prefetching its next
+    // tile's first chunk during the current tile's last -- for plain single-source layers with several tiles per workgroup.
+    // Not under the patch lanes: a persistent grid holds every CU until it ends, and the lanes live on the small launches of one
+    // patch slipping in beside the large ones of its neighbour.
+    a.n_tiles = 0;
+    {
+        const long long nt = (long long)a.tiles_x * a.tiles_y * gz;
+        const int slots = ctx->n_cus * (ks.WAVES == 8 ? 1 : 2);
+        const bool plain = !a.in2 && a.KZ <= 1 && a.Din <= 1;
+        const bool eligible = next_ok && plain && ks.epi != EPI_HEAD && a.cog_inner == 1 && nt < (1LL << 30);
+        // (measured, profiles/r03_persistent_ab.txt: +5 .. +60 % on the tiles of up to 96 channels, whose prologue is 10 - 20 % of
+        // a tile; +-0 on the 128-channel 8-wave tiles, where the longer scalar state costs the K loop what the prologue gave)
+        const bool want = ctx->persist_mode == 2 || (ctx->persist_mode == 1 && !ctx->lanes_on && nt >= 2LL * slots && ks.MT <= 96);
+        if (eligible && want) {
+            const int wgs = ctx->persist_wgs > 0 ? ctx->persist_wgs : slots;
+            a.n_tiles = (int)nt;
+            grid = dim3((unsigned)std::max(8, wgs / 8 * 8), 1, 1);
+        }
+    }
+    // algorithmic HBM bytes of the launch: the input window (with its halo) of every source once, the weights once, the output
+    // window once (+ the residual it adds); 4 bytes per element in either format
+    double bytes = 0;
+    {
+        const double wy = a.wy1 - a.wy0, wx = a.wx1 - a.wx0, span = (double)ks.D * (ks.K - 1), spanx = (double)ks.D * (ks.KX - 1);
+        const double planes = (double)a.Dout * std::max(a.nphase, 1);
+        bytes += (double)a.cells_in * 32.0 * std::min((double)a.Hin, wy + span) * std::min((double)a.Win, wx + spanx) * (a.Din > 1 ? a.Din : 1);
+        const double outpx = wy * wx * planes * (a.os > 1 && a.nphase == 0 && a.subpix_cout > 0 ? 4.0 : 1.0);
+        bytes += (a.out_f32 ? 4.0 * a.Cout : a.head_out ? 4.0 : 32.0 * a.cells_out) * outpx;
+        if (a.res) bytes += 32.0 * a.cells_out * outpx;
+        bytes += (double)n_cog * ks.stages(a.cells_in * std::max(a.KZ, 1)) * ks.W_STEP_BYTES * std::max(a.nphase, 1);
+    }
+    prof_begin(ctx, 0, flops, ks.name, bytes);
     hipError_t e = ks.launch(a, grid, ctx->stream);
     prof_end(ctx);
     HIPCHK(ctx, e);
@@ -1453,7 +1497,10 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     set_window(a, w, 1, 2 * L.pad);       // Y columns x .. x + k - 1 feed output column x
     int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
     if (!rc) {
-        prof_begin(ctx, 2, 0);
+        // (labelled: an HBM-bound kernel whose bandwidth bench.py reports -- reads k planes of Wp columns, writes one of W)
+        const double ss_rows = w.on ? (double)(w.y1 - w.y0) : (double)rows, ss_cols = w.on ? (double)(w.x1 - w.x0) : (double)dst.W;
+        prof_begin(ctx, 2, 0, "shiftsum (last conv: sum of the k column-kernel planes + bias + un-normalisation)",
+                   4.0 * ss_rows * ((double)L.k * (ss_cols + 2 * L.pad) + ss_cols));
         hipError_t e = w.on ? launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out,
                                               ctx->stream, (size_t)w.y0, (size_t)w.y1, w.x0, w.x1)
                             : launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream);
@@ -1805,6 +1852,7 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
             return fail(nullptr, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
                         prop.gcnArchName);
         }
+        if (prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
     }
     if (hipStreamCreate(&ctx->own_stream) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreate failed"); }
     ctx->stream = ctx->own_stream;
@@ -1840,7 +1888,7 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipFree(ctx->d_zeros);
     (void)hipFree(ctx->d_flag);
     (void)hipHostFree(ctx->h_flag);
-    for (auto& e : ctx->split_plans) (void)hipFree(e.second);
+    for (auto& e : ctx->split_plans) (void)hipFree(e.d);
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -1982,6 +2030,12 @@ int tpz_ctx_set_lanes(tpz_ctx* ctx, int on) {
     return 0;
 }
 
+int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups) {
+    if (!ctx || mode < 0 || mode > 2 || workgroups < 0) return fail(ctx, "tpz_ctx_set_persist: bad arguments");
+    ctx->persist_mode = mode;
+    ctx->persist_wgs = workgroups;
+    return 0;
+}
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on) {
     if (!ctx) return 1;
     ctx->roi_enabled = on != 0;
@@ -2757,6 +2811,17 @@ int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches,
         name[0] = 0;
         if (have) snprintf(name, name_len, "%s", (const char*)order[rank].first);
     }
+    return 0;
+}
+int tpz_prof_get_kernel_bytes(tpz_ctx* ctx, int rank, double* bytes) {
+    if (!ctx || rank < 0 || !bytes) return fail(ctx, "tpz_prof_get_kernel_bytes: bad arguments");
+    prof_flush(ctx);
+    std::vector<std::pair<const void*, ProfAcc>> order(ctx->per_kernel);
+    std::stable_sort(order.begin(), order.end(),
+                     [](const std::pair<const void*, ProfAcc>& x, const std::pair<const void*, ProfAcc>& y) {
+                         return x.second.ms > y.second.ms;
+                     });
+    *bytes = rank < (int)order.size() ? order[rank].second.bytes : 0.0;
     return 0;
 }
 int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len) {

@@ -19,6 +19,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        pin_this_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if (world > 1 or os.environ.get('TOPAZ_AMD_FORCE_DIST') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -46,6 +48,84 @@ def free_port() -> int:
     return port
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def cpu_sets_for_ranks(n: int, sysfs: str = '/sys', allowed: Optional[Sequence[int]] = None) -> List[List[int]]:
+    """Host placement of n rank processes on one node: rank r gets CPUs of the NUMA node GPU r hangs off (the amdgpu render
+    devices of /sys/class/drm in card order, their device/numa_node, that node's cpulist), the GPUs of one node sharing its CPUs
+    in equal contiguous slices -- each rank's launch thread (~700 kernel launches per micrograph) and reader thread then stay
+    next to their GPU's PCIe root and off the other ranks' cores.  Fallback when the topology cannot be read (no sysfs entry,
+    numa_node -1, fewer GPUs listed than ranks): the allowed CPUs cut into n equal contiguous slices.  Pure function of the
+    sysfs tree (tests feed it a fake one)."""
+    import glob
+    if allowed is None:
+        try:
+            allowed = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            allowed = list(range(os.cpu_count() or 1))
+    allowed = list(allowed)
+
+    def even_slices(cpus: Sequence[int], k: int) -> List[List[int]]:
+        cpus = list(cpus)
+        if len(cpus) < k:
+            return [cpus for _ in range(k)]
+        return [cpus[i * len(cpus) // k:(i + 1) * len(cpus) // k] for i in range(k)]
+
+    nodes: List[int] = []
+    try:
+        cards = sorted(glob.glob(os.path.join(sysfs, 'class/drm/card[0-9]*')),
+                       key=lambda p: int(''.join(ch for ch in os.path.basename(p) if ch.isdigit())))
+        for c in cards:
+            if '-' in os.path.basename(c):                       # connectors (card0-DP-1), not devices
+                continue
+            drv = os.path.join(c, 'device/driver')
+            if os.path.exists(drv) and os.path.basename(os.path.realpath(drv)) != 'amdgpu':
+                continue
+            nodes.append(int(open(os.path.join(c, 'device/numa_node')).read().strip()))
+    except (OSError, ValueError):
+        nodes = []
+    if len(nodes) < n or any(v < 0 for v in nodes[:n]):
+        return even_slices(allowed, n)
+    nodes = nodes[:n]
+    out: List[List[int]] = [[] for _ in range(n)]
+    for node in sorted(set(nodes)):
+        try:
+            cpus = [c for c in _parse_cpulist(open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')).read())
+                    if c in set(allowed)]
+        except (OSError, ValueError):
+            return even_slices(allowed, n)
+        ranks = [r for r in range(n) if nodes[r] == node]
+        if not cpus:
+            return even_slices(allowed, n)
+        for r, sl in zip(ranks, even_slices(cpus, len(ranks))):
+            out[r] = sl
+    return out
+
+
+def pin_this_rank(local_rank: int, local_world: int) -> Optional[List[int]]:
+    """host placement of a rank that somebody else started (torchrun): the same CPU set launch_local_ranks would have given
+    it.  No-op when our own launcher pinned it already, when TOPAZ_AMD_NO_AFFINITY=1, or where affinity cannot be set."""
+    if os.environ.get('TOPAZ_AMD_RANK_CPUS') or os.environ.get('TOPAZ_AMD_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        sets = cpu_sets_for_ranks(local_world)
+        if 0 <= local_rank < len(sets) and sets[local_rank]:
+            os.sched_setaffinity(0, set(sets[local_rank]))
+            os.environ['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, sets[local_rank]))
+            return sets[local_rank]
+    except OSError:
+        pass
+    return None
+
+
 def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
     """One process per GPU without an external launcher: start `n` copies of `argv` (a full command line, e.g.
     [sys.executable, 'bench.py', '--gpus', '8']) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
@@ -59,10 +139,16 @@ def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, 
     base.update(WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()))
     base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     procs = []
+    # host placement: rank r on the CPUs next to GPU r (cpu_sets_for_ranks; TOPAZ_AMD_NO_AFFINITY=1 leaves the ranks unpinned)
+    cpu_sets = None if base.get('TOPAZ_AMD_NO_AFFINITY') == '1' else cpu_sets_for_ranks(n)
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        pin = None
+        if cpu_sets and cpu_sets[r] and hasattr(os, 'sched_setaffinity'):
+            e['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, cpu_sets[r]))
+            pin = (lambda cpus: (lambda: os.sched_setaffinity(0, cpus)))(set(cpu_sets[r]))
         # (stdin is not shared: N readers of one pipe would each see a part of it -- the launcher resolves stdin input itself)
-        procs.append(subprocess.Popen(list(argv), env=e, stdin=subprocess.DEVNULL))
+        procs.append(subprocess.Popen(list(argv), env=e, stdin=subprocess.DEVNULL, preexec_fn=pin))
     t0 = time.time()
     codes: List[Optional[int]] = [None] * n
     try:
@@ -110,6 +196,25 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sum_over_ranks(value: float, device: torch.device) -> float:
+    """all_reduce(SUM) of one number; `value` itself without a process group"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_scalars(value: float, device: torch.device) -> List[float]:
+    """every rank's number, on every rank (one all_gather)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def sum_to_root(t: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:

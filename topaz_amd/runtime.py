@@ -78,6 +78,11 @@ class Context:
         """patch windows of tpz_denoise_2d: each layer of a patch computes only what the kept centre depends on (default on)"""
         check(self.lib.tpz_ctx_set_roi(self.handle, 1 if on else 0), self.handle)
 
+    def set_persist(self, mode: int = 1, workgroups: int = 0) -> None:
+        """persistent workgroups of the 2xf16 convolutions: 0 never, 1 large launches (default), 2 every eligible launch with
+        `workgroups` workgroups (0: one per grid slot)"""
+        check(self.lib.tpz_ctx_set_persist(self.handle, int(mode), int(workgroups)), self.handle)
+
     def prof_get(self, cls: int) -> Tuple[float, int, float]:
         ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
         check(self.lib.tpz_prof_get(self.handle, cls, C.byref(ms), C.byref(n), C.byref(fl)), self.handle)
@@ -106,8 +111,20 @@ def _prof_kernels(self):
         out.append((buf.value.decode(), ms.value, n.value, fl.value))
 
 
+def _prof_kernels_bytes(self):
+    """[(name, total ms, launches, FLOP, algorithmic HBM bytes)]: prof_kernels() plus the bytes each instantiation's launches
+    read and wrote once (inputs with halo, weights, outputs) -- the bandwidth of the HBM-bound kernels"""
+    out = []
+    for rank, (name, ms, n, fl) in enumerate(self.prof_kernels()):
+        b = C.c_double()
+        check(self.lib.tpz_prof_get_kernel_bytes(self.handle, rank, C.byref(b)), self.handle)
+        out.append((name, ms, n, fl, b.value))
+    return out
+
+
 Context.prof_get_dominant = _prof_get_dominant
 Context.prof_kernels = _prof_kernels
+Context.prof_kernels_bytes = _prof_kernels_bytes
 
 
 def get_context(device: Optional[int] = None) -> Context:
