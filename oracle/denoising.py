@@ -34,9 +34,12 @@ def _up_cat(h, skip):
     return torch.cat([h, skip], 1)
 
 
-def unet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], depth: int = 5, dims: int = 2) -> torch.Tensor:
+def unet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], depth: int = 5, dims: int = 2, no_skip=(),
+                 noise_only: bool = False) -> torch.Tensor:
     """UDenoiseNet (depth 5: enc1..enc6, dec5..dec1), UDenoiseNetSmall (depth 3: enc1..enc4, dec3..dec1)
-    and UDenoiseNet3D (depth 5, dims 3).  x: [N,1,(D,)H,W]."""
+    and UDenoiseNet3D (depth 5, dims 3).  x: [N,1,(D,)H,W].
+    no_skip: decoder levels that upsample WITHOUT concatenating the skip tensor -- UDenoiseNet2 (models.py:321-338: dec2 and
+    dec1).  noise_only: UDenoiseNet3 (models.py:447) returns x - dec1(h)."""
     lrelu = lambda t: F.leaky_relu(t, 0.1)
     skips = [x]
     h = x
@@ -46,12 +49,15 @@ def unet_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], depth: int = 5, d
     h = lrelu(_conv(skips[-1], sd, f'enc{depth + 1}.0', dims))
     # decoder level L concatenates with skip p_{L-1}; dec1 concatenates with the input itself
     for lvl in range(depth, 0, -1):
-        h = _up_cat(h, skips[lvl - 1])
+        if lvl in no_skip:
+            h = F.interpolate(h, size=tuple(skips[lvl - 1].shape[2:]), mode='nearest')
+        else:
+            h = _up_cat(h, skips[lvl - 1])
         h = lrelu(_conv(h, sd, f'dec{lvl}.0', dims))
         h = lrelu(_conv(h, sd, f'dec{lvl}.2', dims))
         if lvl == 1:
             h = _conv(h, sd, 'dec1.4', dims)       # no activation after the last conv
-    return h
+    return x - h if noise_only else h
 
 
 def fcnn_forward(x, sd):
@@ -71,6 +77,10 @@ def model_forward(kind: str, sd, x: torch.Tensor) -> torch.Tensor:
         return unet_forward(x, sd, 5, 2)
     if kind == 'unet-small':
         return unet_forward(x, sd, 3, 2)
+    if kind == 'unet2':
+        return unet_forward(x, sd, 5, 2, no_skip=(2, 1))
+    if kind == 'unet3':
+        return unet_forward(x, sd, 5, 2, noise_only=True)
     if kind == 'unet-3d':
         return unet_forward(x, sd, 5, 3)
     if kind == 'fcnn':

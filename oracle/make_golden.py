@@ -314,6 +314,31 @@ def scoring3d():
         save('score_' + name, **arrays)
 
 
+def scoring3d_basic():
+    """3-D BasicConv stacks (basic.py:12-111 with dims = 3; `topaz train -m conv31 --dims 3` builds them through
+    factory.conv31(units, dims=3, ...)): LinearClassifier(BasicConv([7, 5, 5] / [7, 5, 5, 5], dims=3)), BN + PReLU, seeded,
+    filled, on small tomograms."""
+    from topaz.model.classifier import LinearClassifier
+    from topaz.model.features.basic import BasicConv
+    rs = np.random.RandomState(95)
+    for name, sizes, units, shape in (('conv31_3d_bn_u8', [7, 5, 5], 8, (14, 20, 26)), ('conv63_3d_bn_u8', [7, 5, 5, 5], 8, (10, 12, 40))):
+        torch.manual_seed(96 + len(sizes))
+        m = LinearClassifier(BasicConv(sizes, units, dims=3), dims=3)
+        randomise_bn(m, 97)
+        g = torch.Generator().manual_seed(98)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.PReLU):
+                mod.weight.data = 0.05 + 0.4 * torch.rand(mod.weight.shape, generator=g)
+        m.eval()
+        m.fill()
+        x = rs.randn(*shape).astype(np.float32)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x)[None, None])[0, 0].numpy()
+        save('score_' + name, arch=np.asarray(name.split('_')[0]), x0=x, y0=y, **sd_arrays(m))
+        if name.startswith('conv31'):
+            torch.save(m, os.path.join(OUT, 'user_model_conv31_3d_bn_u8.sav'))
+
+
 def extras():
     """rows the first round left partial: the radius search / validation of `topaz extract --targets`
     (extract.py:135-204,284-305), `topaz segment` score maps (model/utils.py:71-105), the inverse-Gaussian pre-filter.
@@ -482,6 +507,24 @@ def normalize():
              mus=md['mus'], stds=md['stds'], pis=md['pis'], logps=md['logps'])
     y, md = ref_normalize(x.copy(), method='affine')
     save('normalize_affine', x=x, y=y, mu=np.asarray(md['mu']), std=np.asarray(md['std']))
+
+
+def denoise2d_user_archs():
+    """the user-trainable denoiser classes besides UDenoiseNet (`topaz denoise --arch unet2 | unet3`, commands/denoise.py:56;
+    denoising/models.py:247-449), seeded: outputs of the reference's own modules + the full-module pickles `train_model` would
+    have written (models.py:628-633).  DenoiseNet (--arch fcnet) is not here: its forward pass raises upstream (a 3*nf-channel
+    tensor fed to Conv2d(nf, 2*nf), models.py:38-39)."""
+    from topaz.denoise import Denoise
+    from topaz.denoising.models import UDenoiseNet2, UDenoiseNet3
+    x = image(61, 150, 133)
+    for tag, ctor, seed in (('unet2_nf12', lambda: UDenoiseNet2(nf=12), 71), ('unet3', lambda: UDenoiseNet3(), 72)):
+        torch.manual_seed(seed)
+        net = ctor().eval()
+        dn = Denoise.__new__(Denoise)
+        dn.model, dn.device, dn.dims, dn.use_cuda = net, torch.device('cpu'), 2, False
+        torch.save(net, os.path.join(OUT, f'user_model_{tag}.sav'))
+        # (the weights travel in the pickle only: tests read them back through topaz_amd's own unpickler)
+        save(f'denoise2d_{tag}', x=x, whole=dn.denoise(x, patch_size=-1), p96_24=dn.denoise(x, 96, 24))
 
 
 if __name__ == '__main__':

@@ -151,7 +151,9 @@ def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5,
     for k, s in zip(sizes[::-1], strides[::-1]):
         width = (width - 1) * s + 1 + (k - 1)
     p = width // 2
-    h = F.pad(x, (p, p, p, p))
+    dims = sd[f'{prefix}0.weight'].dim() - 2          # Conv2d or Conv3d weights (basic.py:19-27)
+    conv = F.conv3d if dims == 3 else F.conv2d
+    h = F.pad(x, (p, p) * dims)
     # fill() zips the layers with `strides`, which has no entry for Dropout layers (basic.py:57-58,69-70,81-89): a model
     # built with dropout > 0 gets the dilations this slipped walk gives (conv31: 1,4,4), any other 1,2,4,...
     kinds, zs = [], []
@@ -166,7 +168,7 @@ def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5,
     dils += [1] * (len(sizes) - len(dils))
     idx = 0
     for dil in dils:
-        h = F.conv2d(h, sd[f'{prefix}{idx}.weight'], sd.get(f'{prefix}{idx}.bias'), dilation=dil)
+        h = conv(h, sd[f'{prefix}{idx}.weight'], sd.get(f'{prefix}{idx}.bias'), dilation=dil)
         idx += 1
         if has_bn:
             h = _bn(h, sd, f'{prefix}{idx}')
@@ -174,7 +176,7 @@ def basicconv_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], sizes=(7, 5,
         h = F.prelu(h, sd[f'{prefix}{idx}.weight'])
         idx += 1 + (1 if dropout else 0)              # (Dropout: identity in eval mode)
     if head:
-        h = F.conv2d(h, sd['classifier.weight'], sd['classifier.bias'])
+        h = conv(h, sd['classifier.weight'], sd['classifier.bias'])
     return h
 
 

@@ -218,8 +218,9 @@ def test_unpickler_nested_payload_stays_inside_the_allowlist(tmp_path):
 
 
 def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
-    """UDenoiseNet3 (--arch unet3) has UDenoiseNet's parameter names but returns x - dec1(h): it must be refused, not
-    evaluated as a UDenoiseNet.  The classes are faked under the reference's module path for pickling."""
+    """UDenoiseNet3 (--arch unet3) has UDenoiseNet's parameter names but returns x - dec1(h): the pickled CLASS decides which
+    forward pass is built, never the parameter names alone; DenoiseNet (--arch fcnet), whose forward pass
+    raises upstream, and unknown classes are refused.  The classes are faked under the reference's module path for pickling."""
     import sys
     import types
     import torch
@@ -240,7 +241,7 @@ def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
     try:
         sys.modules.update(pkgs)
         sys.modules['topaz.denoising.models'] = fake
-        for name in ('UDenoiseNet', 'UDenoiseNet3'):
+        for name in ('UDenoiseNet', 'UDenoiseNet3', 'DenoiseNet', 'UDenoiseNetX'):
             m = make(name)()
             for k, v in sd.items():
                 blk, idx, leaf = k.split('.')
@@ -262,5 +263,9 @@ def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
     got = {}
     _walk(obj, '', got)
     assert _kind_from_class(obj, got, 'x') == 'unet' and set(got) == set(sd)
-    with pytest.raises(NotImplementedError, match='UDenoiseNet3'):
-        load_model(saved['UDenoiseNet3'])
+    obj3 = torch.load(saved['UDenoiseNet3'], map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    assert _kind_from_class(obj3, got, 'x') == 'unet3'
+    with pytest.raises(NotImplementedError, match='fcnet'):
+        load_model(saved['DenoiseNet'])
+    with pytest.raises(NotImplementedError, match='UDenoiseNetX'):
+        load_model(saved['UDenoiseNetX'])

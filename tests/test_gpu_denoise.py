@@ -79,6 +79,26 @@ def test_user_model_pickle(gpu_ctx):
     assert _err(d.denoise(z['x'], 48, 20), z['p48_20']) <= ATOL
 
 
+@pytest.mark.parametrize('tag', ['unet2_nf12', 'unet3'])
+def test_user_trainable_archs_unet2_unet3_pickles(gpu_ctx, tag):
+    """`topaz denoise --arch unet2 | unet3` models (denoising/models.py:247-449) loaded from their full-module pickles by class
+    name: UDenoiseNet2 drops the skip connections into dec2 / dec1, UDenoiseNet3 returns x - dec1(h) (the residual is added in
+    the last conv's epilogue).  Against the reference's own outputs, default path and exact-fp32 path."""
+    import os
+    from conftest import GOLDEN
+    from topaz_amd.denoise import Denoise
+    z = load_golden(f'denoise2d_{tag}')
+    d = Denoise(os.path.join(GOLDEN, f'user_model_{tag}.sav'))
+    assert d.model.kind == tag.split('_')[0]
+    for exact in (False, True):
+        gpu_ctx.set_exact(exact)
+        try:
+            assert _err(d.denoise(z['x'], -1), z['whole']) <= ATOL
+            assert _err(d.denoise(z['x'], 96, 24), z['p96_24']) <= ATOL
+        finally:
+            gpu_ctx.set_exact(False)
+
+
 def test_unet3d_nf48_tile_vs_oracle(gpu_ctx):
     """the pretrained 3-D architecture (nf 48, base 7; blob missing upstream) with seeded weights on
     one 64^3 tile through Denoise3D._denoise, and a 2x2x1 tile grid with 32/16 patches"""

@@ -31,7 +31,7 @@ def test_scoring_pretrained(name):
 
 
 @pytest.mark.parametrize('name', ['resnet8_bn_u16', 'resnet16_u16', 'conv127_bn_u16', 'conv31_u32', 'resnet8_3d_u8',
-                                  'resnet8_3d_bn_u8', 'resnet16_3d_u8'])
+                                  'resnet8_3d_bn_u8', 'resnet16_3d_u8', 'conv31_3d_bn_u8', 'conv63_3d_bn_u8'])
 def test_scoring_seeded(name):
     z = load_golden(f'score_{name}')
     y = scoring.score(str(z['arch']), golden_sd(z), z['x0'])
@@ -134,6 +134,24 @@ def test_denoise2d_seeded_v022_arch():
     sd = golden_sd(z)
     np.testing.assert_allclose(denoising.denoise('unet', sd, z['x'], -1), z['whole'], atol=2e-5, rtol=0)
     np.testing.assert_allclose(denoising.denoise('unet', sd, z['x'], 48, 20), z['p48_20'], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize('tag,kind', [('unet2_nf12', 'unet2'), ('unet3', 'unet3')])
+def test_denoise2d_user_trainable_archs(tag, kind):
+    """UDenoiseNet2 (--arch unet2: no skip into dec2 / dec1) and UDenoiseNet3 (--arch unet3: x - dec1(h)),
+    denoising/models.py:247-449: the oracle against the reference's own modules, weights read from the full-module pickle
+    through topaz_amd's allow-listing unpickler (no reference import)"""
+    import os
+    import torch
+    from collections import OrderedDict
+    from conftest import GOLDEN
+    from topaz_amd.model.unpickle import _PickleModule, _walk
+    z = load_golden(f'denoise2d_{tag}')
+    obj = torch.load(os.path.join(GOLDEN, f'user_model_{tag}.sav'), map_location='cpu', weights_only=False, pickle_module=_PickleModule)
+    sd = OrderedDict()
+    _walk(obj, '', sd)
+    assert np.abs(denoising.denoise(kind, sd, z['x'], -1) - z['whole']).max() <= 2e-5
+    assert np.abs(denoising.denoise(kind, sd, z['x'], 96, 24) - z['p96_24']).max() <= 2e-5
 
 
 def test_denoise3d_seeded():

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, cons
     }
     float v = acc;
     if (a.bias) v += a.bias[co];
+    // residual [Cout][Dres][Hres][Wres], centre-cropped by res_crop (ResidA; UDenoiseNet3's x - dec1(h) with negated weights)
+    if (a.res) v += a.res[(((size_t)co * a.Dres + oz + (a.Dres > 1 ? a.res_crop : 0)) * a.Hres + oy + a.res_crop) * a.Wres + ox + a.res_crop];
     v = v > 0.f ? v : v * a.slope;
     if (a.norm_out) v = v * out_scale + out_shift;
     a.out[((size_t)co * a.Dout + oz) * a.Hout * a.Wout + (size_t)oy * a.Wout + ox] = v;
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
             if (ox < a.Wout) {
                 float v = acc[p];
                 if (a.bias) v += a.bias[0];
+                if (a.res) v += a.res[(((size_t)oz + (a.Dres > 1 ? a.res_crop : 0)) * a.Hres + oy + a.res_crop) * a.Wres + ox + a.res_crop];
                 v = v > 0.f ? v : v * a.slope;
                 if (a.norm_out) v = v * out_scale + out_shift;
                 a.out[((size_t)oz * a.Hout + oy) * a.Wout + ox] = v;
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
 __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
                                                        size_t rows, int W, int Wp, float bias,
                                                        const float* __restrict__ nrm, int norm_out, size_t y0, size_t y1,
-                                                       int x0, int x1) {
+                                                       int x0, int x1, const float* __restrict__ res) {
     const int nx = x1 - x0;
     const size_t n = (y1 - y0) * nx;
     float sc = 1.f, sh = 0.f;
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__
         const size_t row = y0 + i / nx;
         float acc = 0.f;
         for (int v = 0; v < K; ++v) acc += Y[((size_t)v * rows + row) * Wp + x + v];
+        if (res) acc += res[row * W + x];          // (same-size residual: UDenoiseNet3's x - dec1(h), weights negated)
         out[row * W + x] = (acc + bias) * sc + sh;
     }
 }
@@ -618,13 +622,13 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
     return hipGetLastError();
 }
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
-                           int norm_out, hipStream_t s, size_t y0, size_t y1, int x0, int x1) {
+                           int norm_out, hipStream_t s, size_t y0, size_t y1, int x0, int x1, const float* res) {
     if (y1 > rows) y1 = rows;
     if (x1 > W) x1 = W;
     const size_t n = (y1 - y0) * (size_t)(x1 - x0);
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out,
-                       y0, y1, x0, x1);
+                       y0, y1, x0, x1, res);
     return hipGetLastError();
 }
 

@@ -568,9 +568,9 @@ static int prepare_layer(tpz_ctx* ctx, tpz_model* m, const tpz_layer& L, const f
         if (upload(ctx, m, packed.data(), packed.size(), &rt.d_wpk)) return 1;
         if (!g_no_phase && prepare_phases(ctx, m, L, w, c1, c2, rt)) return 1;
     } else {
-        if (L.src2 >= 0 || L.res >= 0 || L.head || L.post_scale_off >= 0)
+        if (L.src2 >= 0 || L.head || L.post_scale_off >= 0)
             return fail(ctx, "conv k=%d dil=%d cin=%d cout=%d dims=%d: no MFMA kernel compiled and the direct "
-                        "kernel has no concat/residual/head epilogue", L.k, L.dil, L.cin, L.cout, L.dims);
+                        "kernel has no concat/head/affine epilogue", L.k, L.dil, L.cin, L.cout, L.dims);
         if (upload(ctx, m, w, wn, &rt.d_wpk)) return 1;
     }
     if (L.b_off >= 0) {
@@ -878,7 +878,7 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         // the split epilogue applies the activation as max(v, slope * v): right for every slope <= 1 (ReLU, LeakyReLU,
         // identity, PReLU as trained); a layer with a larger slope stays on its fp32 kernel
         if (L.op == TPZ_OP_CONV && L.slope > 1.f) continue;
-        if (L.op == TPZ_OP_CONV && !rt.ki && L.cout == 1 && L.cin % 8 == 0 && L.src2 < 0 && L.res < 0 && !L.head &&
+        if (L.op == TPZ_OP_CONV && !rt.ki && L.cout == 1 && L.cin % 8 == 0 && L.src2 < 0 && (L.res < 0 || L.res_crop == 0) && !L.head &&
             L.post_scale_off < 0 && L.dil == 1 && L.pad == L.k / 2 && L.slope == 1.f && i == nl - 1) {
             // 1-output-channel last conv: its kx taps as k virtual output channels of a k x 1 column kernel
             rt.ks_last = find_split(L.k, 1, 16, EPI_PLAIN_F32, 1);
@@ -1467,7 +1467,8 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
 
 // 1-output-channel last conv on the 2xf16 path: k virtual output channels (one per kx tap) over W + 2*pad columns
 // by a k x 1 column kernel storing fp32, then out[x] = sum_v Y[v][x + v] + bias (and the un-normalisation)
-static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst, const float* d_nrm, int norm_out) {
+static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst, const float* d_nrm, int norm_out,
+                          const Slot* sres = nullptr) {
     const tpz_layer& L = rt.L;
     const SplitKernelInfo& ks = *rt.ks_last;
     const int Wp = dst.W + 2 * L.pad;
@@ -1501,9 +1502,12 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
         const double ss_rows = w.on ? (double)(w.y1 - w.y0) : (double)rows, ss_cols = w.on ? (double)(w.x1 - w.x0) : (double)dst.W;
         prof_begin(ctx, 2, 0, "shiftsum (last conv: sum of the k column-kernel planes + bias + un-normalisation)",
                    4.0 * ss_rows * ((double)L.k * (ss_cols + 2 * L.pad) + ss_cols));
+        // (a residual of the output's own size -- UDenoiseNet3: x - dec1(h), weights negated -- is added here, in fp32)
+        const float* resp = sres ? sres->p : nullptr;
         hipError_t e = w.on ? launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out,
-                                              ctx->stream, (size_t)w.y0, (size_t)w.y1, w.x0, w.x1)
-                            : launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream);
+                                              ctx->stream, (size_t)w.y0, (size_t)w.y1, w.x0, w.x1, resp)
+                            : launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream,
+                                              0, (size_t)-1, 0, 0x7fffffff, resp);
         prof_end(ctx);
         if (e != hipSuccess) rc = fail(ctx, "shiftsum failed: %s", hipGetErrorString(e));
     }
@@ -1746,11 +1750,11 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             v1.p = slot_as(ctx, slots[L.src], want1);
             v1.split = want1;
             if (s2) { v2 = *s2; v2.p = slot_as(ctx, slots[L.src2], want2); v2.split = want2; }
-            if (sres) { vres = *sres; vres.p = slot_as(ctx, slots[L.res], use_split); vres.split = use_split; }
+            if (sres) { vres = *sres; vres.p = slot_as(ctx, slots[L.res], use_split && !use_last); vres.split = use_split && !use_last; }
             if (!v1.p || (s2 && !v2.p) || (sres && !vres.p)) { rc = fail(ctx, "layer %d: tensor format conversion failed", i); break; }
             // slot 0 arrives already normalised (denoise_region); only the last layer un-normalises
             if (use_stem) rc = run_stem_split(ctx, rt, v1, dst, fuse_pool);
-            else if (use_last) rc = run_last_split(ctx, rt, v1, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0);
+            else if (use_last) rc = run_last_split(ctx, rt, v1, dst, d_nrm, (d_nrm && i == nl - 1) ? 1 : 0, sres ? &vres : nullptr);
             else if (use_sphase) rc = run_conv_split_phases(ctx, rt, v1, v2, dst);
             else if (use_split && fold_here) {
                 Slot vf = slots[rt.fold_src];

@@ -43,6 +43,10 @@ _ARCH = {
 def _program(kind: str, sd) -> LayerProgram:
     if kind == 'unet':
         return pack.pack_unet(sd, 5, 2)
+    if kind == 'unet3':
+        return pack.pack_unet(sd, 5, 2, noise_only=True)
+    if kind == 'unet2':
+        return pack.pack_unet(sd, 5, 2, no_skip=(2, 1))
     if kind == 'unet-small':
         return pack.pack_unet(sd, 3, 2)
     if kind == 'unet-3d':
@@ -137,19 +141,29 @@ def load_model(name, base_kernel_width: int = 11) -> DenoiseNet:
 _CLASS_KIND = {
     'UDenoiseNet': 'unet',
     'UDenoiseNetSmall': 'unet-small',
+    'UDenoiseNet2': 'unet2',          # --arch unet2: no skip connection into dec2 / dec1 (models.py:247-336)
+    'UDenoiseNet3': 'unet3',          # --arch unet3: predicts the noise, returns x - dec1(h) (models.py:339-449)
     'DenoiseNet2': 'fcnn',
     'UDenoiseNet3D': 'unet-3d',
     'AffineDenoise': 'affine',
 }
+# what the parameter names alone look like for each class (several classes share a layout)
+_KEY_LAYOUT = {'unet2': 'unet', 'unet3': 'unet'}
 
 
 def _kind_from_class(obj, sd, path) -> str:
     qn = getattr(type(obj), '_tpz_qualname', '') or type(obj).__name__
     cls = qn.rsplit('.', 1)[-1]
+    if cls == 'DenoiseNet':
+        # --arch fcnet: its Sequential feeds a 3*nf-channel tensor into Conv2d(nf, 2*nf) (models.py:38-39) -- the forward pass
+        # raises RuntimeError upstream for every width, so no such model can have been trained
+        raise NotImplementedError(f'{path}: topaz.denoising.models.DenoiseNet (--arch fcnet) cannot be evaluated: its layer '
+                                  f'list is inconsistent upstream (denoising/models.py:25-49, channel mismatch at net.10)')
     if cls not in _CLASS_KIND:
         raise NotImplementedError(f'{path}: denoising model class {cls} is not supported on the MI355X path '
                                   f'(supported: {", ".join(sorted(_CLASS_KIND))})')
-    kind = _kind_from_state_dict(sd)
-    if kind != _CLASS_KIND[cls]:
-        raise ValueError(f'{path}: a {cls} whose parameters look like a {kind!r} network')
+    kind = _CLASS_KIND[cls]
+    layout = _kind_from_state_dict(sd)
+    if layout != _KEY_LAYOUT.get(kind, kind):
+        raise ValueError(f'{path}: a {cls} whose parameters look like a {layout!r} network')
     return kind

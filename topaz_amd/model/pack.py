@@ -167,14 +167,17 @@ def basic_fill_dilations(n_convs: int, has_bn: bool, dropout: bool = False) -> L
     return dils + [1] * (n_convs - len(dils))        # convs past the end of the zip keep dilation 1 (and their stride 1)
 
 
-def pack_basicconv(sizes: Sequence[int], sd, dropout: bool = False) -> Tuple[LayerProgram, int]:
+def pack_basicconv(sizes: Sequence[int], sd, dropout: bool = False, dims: int = 2) -> Tuple[LayerProgram, int]:
     """filled basic.BasicConv (basic.py:81-89: dilation = cumulative stride 1,2,4,..) + 1x1 head.  `sd` is numbered
-    without Dropout modules (unpickle.py renumbers); `dropout` only selects upstream's fill pattern for such models."""
+    without Dropout modules (unpickle.py renumbers); `dropout` only selects upstream's fill pattern for such models.
+    dims = 3: the same stack over Conv3d / BatchNorm3d weights (basic.py:23-27)."""
     sd = _np(sd)
+    if sd['features.features.0.weight'].ndim != dims + 2:
+        raise ValueError(f'BasicConv stack: the weights are {sd["features.features.0.weight"].ndim - 2}-D, dims = {dims} was asked for')
     has_bn = any(k.endswith('running_mean') for k in sd)
     width = basic_width(sizes)
     dils = basic_fill_dilations(len(sizes), has_bn, dropout)
-    P = LayerProgram(2)
+    P = LayerProgram(dims)
     pre = 'features.features.'
     head_w = sd['classifier.weight'].reshape(-1)
     head_b = float(sd['classifier.bias'].reshape(-1)[0])
@@ -194,26 +197,39 @@ def pack_basicconv(sizes: Sequence[int], sd, dropout: bool = False) -> Tuple[Lay
 
 
 # ---- denoisers -------------------------------------------------------------------------------------
-def pack_unet(sd, depth: int, dims: int = 2) -> LayerProgram:
-    """UDenoiseNet (depth 5), UDenoiseNetSmall (depth 3), UDenoiseNet3D (depth 5, dims 3).
-    Upsample + concat never materialise: the consumer conv reads two sources (src nearest-upsampled)."""
+def pack_unet(sd, depth: int, dims: int = 2, noise_only: bool = False, no_skip=()) -> LayerProgram:
+    """UDenoiseNet (depth 5), UDenoiseNetSmall (depth 3), UDenoiseNet3D (depth 5, dims 3), UDenoiseNet3 (noise_only) and
+    UDenoiseNet2 (no_skip = (2, 1)).
+    Upsample + concat never materialise: the consumer conv reads two sources (src nearest-upsampled).
+    noise_only (UDenoiseNet3, denoising/models.py:447: `y = x - self.dec1(h)`): the last conv runs with negated weights and
+    bias and adds the input as a residual of its own size.
+    no_skip (UDenoiseNet2, models.py:321-338): decoder levels whose first conv reads the upsampled tensor ALONE.  The layer
+    program has no upsample-without-concat; the skip tensor that fixes the upsampled size is concatenated all the same, with
+    zero weights on its channels -- the same sums, a few dead multiply-adds on a user-trained architecture."""
     sd = _np(sd)
     P = LayerProgram(dims)
 
-    def c(src, name, slope=0.1, src2=-1):
+    def c(src, name, slope=0.1, src2=-1, res=-1, negate=False, dead_channels=0):
         w = sd[name + '.weight']
-        return P.conv(src, w, sd.get(name + '.bias'), dil=1, pad=w.shape[-1] // 2, slope=slope, src2=src2)
+        b = sd.get(name + '.bias')
+        if dead_channels:
+            w = np.concatenate([w, np.zeros((w.shape[0], dead_channels) + w.shape[2:], dtype=w.dtype)], axis=1)
+        if negate:
+            w, b = -w, (None if b is None else -b)
+        return P.conv(src, w, b, dil=1, pad=w.shape[-1] // 2, slope=slope, src2=src2, res=res)
 
-    skips = [0]
+    skips, skip_ch = [0], [1]
     h = 0
     for i in range(1, depth + 1):
         h = P.maxpool2(c(h, f'enc{i}.0'))
         skips.append(h)
+        skip_ch.append(sd[f'enc{i}.0.weight'].shape[0])
     h = c(h, f'enc{depth + 1}.0')
     for lvl in range(depth, 0, -1):
-        h = c(h, f'dec{lvl}.0', src2=skips[lvl - 1])
+        dead = skip_ch[lvl - 1] if lvl in no_skip else 0
+        h = c(h, f'dec{lvl}.0', src2=skips[lvl - 1], dead_channels=dead)
         h = c(h, f'dec{lvl}.2')
-    h = c(h, 'dec1.4', slope=1.0)
+    h = c(h, 'dec1.4', slope=1.0, res=0 if noise_only else -1, negate=noise_only)
     return P
 
 
