@@ -154,7 +154,8 @@ def measured_traffic(dom_name: str, args):
     if rec.get('kernel') != dom_name or rec.get('size') != args.size or rec.get('workload') != args.workload:
         return None, None
     return rec.get('traffic_bytes_per_launch'), {k: rec.get(k) for k in (
-        'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'algorithmic_bytes', 'source', 'correction')}
+        'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'algorithmic_bytes', 'source', 'correction',
+        'profiled_at_commit')}
 
 
 def dry_run(args, rank, world):
@@ -410,7 +411,10 @@ def main():
         extras['exact_fp32'] = {'value': args.exact_steps / t, 'ms_per_step': 1e3 * t / args.exact_steps,
                                 'steps': args.exact_steps, 'unit': 'micrographs/s',
                                 'note': 'every convolution on the fp32-MFMA kernels (tpz_ctx_set_exact): exact fp32 '
-                                        'multiplies, peak 157.3 TFLOP/s'}
+                                        'multiplies, peak 157.3 TFLOP/s.  The fp32 kernels compute every tensor of a denoise patch '
+                                        'in full (no patch windows, no fused pool / folded projection): the like-for-like 2xf16 '
+                                        'number is full_patch_tensors, not value',
+                                'like_for_like_with': 'full_patch_tensors'}
         extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
         if args.workload != 'extract':
             # A/B of the patch windows: the same step with every tensor of every denoise patch computed in full

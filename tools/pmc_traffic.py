@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def bench_name(rocprof_name: str):
     """tpz::conv_split_kernel<tpz::SplitCfg<5, 4, 128, 16, 32, 2, 8, 5>, 3, 0>(...) -> the registry name bench.py prints"""
-    m = re.search(r'conv_split_kernel<tpz::SplitCfg<([\d, ]+)>, (\d+), (\d+)>', rocprof_name)
+    m = re.search(r'conv_split_kernel<tpz::SplitCfg<([\d, ]+)>, (\d+), (\d+)(?:, \d+)?>', rocprof_name)
     if not m:
         return None
     k, d, mt, th, tw, cc, w, kx = [int(v) for v in m.group(1).split(',')[:8]]
@@ -47,7 +47,8 @@ def main():
     ap.add_argument('write_dir')
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--workload', default='pipeline')
-    ap.add_argument('--kernel', default=r'SplitCfg<5, 4, 128, 16, 32, 2, 8, 5(, \d+)?>, 3, 0>', help='regex on the rocprofv3 kernel name')
+    ap.add_argument('--kernel', default=r'SplitCfg<5, 4, 128, 16, 32, 2, 8, 5(, \d+)?>, 3, 0(, \d+)?>', help='regex on the rocprofv3 kernel name')
+    ap.add_argument('--commit', default=None, help='commit the profiled build was made from (recorded with the numbers)')
     ap.add_argument('--algorithmic-bytes', type=float, default=None)
     a = ap.parse_args()
     fetch = {k: v for k, v in per_dispatch(a.fetch_dir, 'FETCH_SIZE').items() if re.search(a.kernel, k)}
@@ -64,6 +65,8 @@ def main():
     rec = {
         'kernel': bench_name(name), 'rocprof_kernel': name.split('(')[0], 'size': S, 'workload': a.workload,
         'dispatches': len(fetch[name]),
+        'profiled_at_commit': a.commit or (open(os.path.join(ROOT, 'tools', '_bin', 'HEAD')).read().strip()
+                                           if os.path.exists(os.path.join(ROOT, 'tools', '_bin', 'HEAD')) else None),
         'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_corrected': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
         'traffic_bytes_per_launch': 2 * f_kib * 1024 + w_kib * 1024, 'algorithmic_bytes': alg,
         'correction': 'FETCH_SIZE x 2 (gfx950 tallies the 128-B requests of a 16 B/lane stream at 64 B; MI355X_MICROARCH.md HBM '
