@@ -411,10 +411,10 @@ def main():
         extras['exact_fp32'] = {'value': args.exact_steps / t, 'ms_per_step': 1e3 * t / args.exact_steps,
                                 'steps': args.exact_steps, 'unit': 'micrographs/s',
                                 'note': 'every convolution on the fp32-MFMA kernels (tpz_ctx_set_exact): exact fp32 '
-                                        'multiplies, peak 157.3 TFLOP/s.  The fp32 kernels compute every tensor of a denoise patch '
-                                        'in full (no patch windows, no fused pool / folded projection): the like-for-like 2xf16 '
-                                        'number is full_patch_tensors, not value',
-                                'like_for_like_with': 'full_patch_tensors'}
+                                        'multiplies, peak 157.3 TFLOP/s.  Same patch windows as the 2xf16 path (each layer of a '
+                                        'denoise patch computes the rectangle the kept centre depends on); the max-pools, the 1x1 '
+                                        'projections and the last conv run as layers of their own here (not fused / folded)',
+                                'like_for_like_with': 'value'}
         extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
         if args.workload != 'extract':
             # A/B of the patch windows: the same step with every tensor of every denoise patch computed in full

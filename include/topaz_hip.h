@@ -209,13 +209,14 @@ int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
 /* Patch lanes: tpz_denoise_2d / _3d enqueue the independent patches / tiles of an image alternately on two auxiliary
  * streams (own workspace each), so that one patch's small, latency-bound launches run under its neighbour's large ones.
  * On by default (TPZ_NO_LANES=1 in the environment or on = 0 here: everything on the ctx stream, e.g. to time kernels in
- * isolation).  Results are bit-identical either way. */
+ * isolation).  on = 2 .. 4 (or TPZ_LANES=n): that many lanes; more than two measured no gain on the 4096^2 pipeline
+ * (profiles/r03_lanes.txt).  Results are bit-identical either way. */
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
 /* Patch windows: a patch of tpz_denoise_2d keeps only its centre (topaz/denoise.py:299-323: patch_size pixels of a
  * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the
  * U-Net's receptive field is ~230 pixels, the CLI's default padding 500).  The statistics of the normalisation are still the
  * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
- * (TPZ_NO_ROI=1 in the environment or on = 0 here). */
+ * (TPZ_NO_ROI=1 in the environment or on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones. */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
 /* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
  * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next

@@ -157,12 +157,14 @@ def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):
         assert _err(y[i:i + pz, j:j + py, k:k + px], ref) <= ATOL, (i, j, k)
 
 
+@pytest.mark.parametrize('exact', [False, True], ids=['2xf16', 'exact_fp32'])
 @pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'tight_padding'])
-def test_patch_windows_are_bit_identical(gpu_ctx, case):
+def test_patch_windows_are_bit_identical(gpu_ctx, case, exact):
     """a patch keeps only its centre, so every layer computes only the rectangle the kept pixels depend on
     (runtime.hip need_regions): the output must not change by one bit against computing every tensor in full --
     corner, edge and interior patches, odd sizes (pooled sizes not divisible by two), windows clipped at the borders,
-    padding smaller than the receptive field (nothing to save: the windows must then cover everything)"""
+    padding smaller than the receptive field (nothing to save: the windows must then cover everything).
+    exact_fp32: the same on the fp32-MFMA / direct kernels (tpz_ctx_set_exact), whose launches take the same windows"""
     from topaz_amd.denoise import Denoise
     from topaz_amd.denoising.models import DenoiseNet
     if case == 'bench_net':
@@ -182,17 +184,21 @@ def test_patch_windows_are_bit_identical(gpu_ctx, case):
         shape, patch, pad = (600, 700), 192, 40
     x = (np.random.RandomState(77).randn(*shape) * 3 + 1).astype(np.float32)
     try:
+        gpu_ctx.set_exact(exact)
         gpu_ctx.set_roi(False)
         full = d.denoise(x, patch, pad)
         gpu_ctx.set_roi(True)
         win = d.denoise(x, patch, pad)
     finally:
         gpu_ctx.set_roi(True)
+        gpu_ctx.set_exact(False)
     assert np.isfinite(full).all()
     assert np.array_equal(full, win)
     eligible, split_runs, fp32_reruns = d.model.device_model.split_stats()
     assert fp32_reruns == 0            # (a window never raises the overflow flag on pixels nobody computed)
-    if case != 'fcnn':
+    if exact:
+        assert split_runs == 0
+    elif case != 'fcnn':
         assert eligible and split_runs >= 2
 
 
@@ -208,6 +214,7 @@ def test_patch_windows_random_geometries(gpu_ctx):
             H, W = int(rs.randint(180, 900)), int(rs.randint(180, 900))
             patch, pad = int(rs.randint(48, 320)), int(rs.randint(8, 260))
             x = (rs.randn(H, W) * 2 - 0.5).astype(np.float32)
+            gpu_ctx.set_exact(it >= 6)              # the last four on the fp32 kernels
             gpu_ctx.set_roi(False)
             full = d.denoise(x, patch, pad)
             gpu_ctx.set_roi(True)
@@ -215,6 +222,7 @@ def test_patch_windows_random_geometries(gpu_ctx):
             assert np.array_equal(full, win), (it, H, W, patch, pad)
     finally:
         gpu_ctx.set_roi(True)
+        gpu_ctx.set_exact(False)
 
 
 def test_edge_cases(gpu_ctx):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-instantiation time and achieved TFLOP/s of the convolution kernels for one workload, patch lanes off, measured
-with the library's own HIP-event profiler (tpz_prof_*):   python tools/prof_kernels.py [denoise|extract|denoise3d]"""
+with the library's own HIP-event profiler (tpz_prof_*):   python tools/prof_kernels.py [denoise|extract|denoise3d] [exact]
+(exact: every convolution on the fp32 kernels, tpz_ctx_set_exact)"""
 import os
 import sys
 
@@ -15,8 +16,9 @@ from topaz_amd.denoising.models import DenoiseNet  # noqa: E402
 from topaz_amd.model.classifier import LinearClassifier  # noqa: E402
 
 
-def main(what):
+def main(what, exact=False):
     ctx = rt.get_context(0)
+    ctx.set_exact(exact)
     if what == 'denoise':
         x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
         dn = Denoise(DenoiseNet('unet', sw.unet_sd(11, nf=48, base_width=11, top_width=5)))
@@ -40,7 +42,7 @@ def main(what):
     rows = ctx.prof_kernels()
     ctx.prof_enable(False)
     tot = sum(r[1] for r in rows)
-    print(f'# {what}: {tot:.2f} ms in conv_mfma kernels, {sum(r[3] for r in rows) / 1e12:.2f} TFLOP executed')
+    print(f'# {what}{" (exact fp32)" if exact else ""}: {tot:.2f} ms in conv_mfma kernels, {sum(r[3] for r in rows) / 1e12:.2f} TFLOP executed')
     print(f'{"calls":>6} {"total_ms":>10} {"avg_ms":>9} {"TFLOP/s":>8} {"pct":>6}  kernel')
     for name, ms, n, fl in rows:
         print(f'{n:6d} {ms:10.3f} {ms / n:9.4f} {fl / ms / 1e9:8.1f} {100 * ms / tot:6.2f}  {name}')
@@ -50,4 +52,4 @@ def main(what):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'denoise')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'denoise', 'exact' in sys.argv[2:])

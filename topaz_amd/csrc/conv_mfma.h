@@ -65,6 +65,10 @@ struct ConvArgs {
     int n_chunks;             // channel chunks of NCH channels
     float slope;              // activation: v > 0 ? v : v*slope   (1.0 = identity, 0.0 = ReLU)
     int tiles_x, tiles_y, tiles_z;
+    // launch window (2-D): the outputs [wy0, wy1) x [wx0, wx1) of the launch lattice are computed and stored, the tiles start
+    // at (wy0, wx0).  Whole tensor: 0, 0, Hout, Wout (conv_window_default; wy1 == 0 means "not set").  wx0 % 4 == 0 keeps the
+    // 16-byte granules of the x4 loader aligned.
+    int wy0, wx0, wy1, wx1;
     int xcd_swizzle;          // 1: remap workgroup ids so that each XCD owns a contiguous run of tiles
     int stagger_first;        // workgroups with a linear id below this belong to the first generation
     int stagger_sleeps;       // s_sleep(127) repeats for the odd wave slot of the first generation (0 = off)
@@ -201,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
     const int ty = byz % a.tiles_y;
     const int tz = byz / a.tiles_y;
-    const int y0 = (ty / D) * (C::TH * D) + (ty % D);
+    const int y0 = a.wy0 + (ty / D) * (C::TH * D) + (ty % D);
     const int z0 = (C::DIMS == 3) ? (tz / D) * (C::TD * D) + (tz % D) : 0;
-    const int x0 = bx * C::TW;
+    const int x0 = a.wx0 + bx * C::TW;
     // The LDS tile starts PADA = roundup4(pad) pixels left of x0, so every 4-float LDS granule maps to a
     // 16-byte aligned global run when the row pitch is a multiple of 4 floats; B reads shift by PADA - pad.
     const int pada = (a.pad_x + 3) & ~3;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int ti_z = trow / C::TH, ti_y = trow % C::TH;
             const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
             const int ox = x0 + (n % NFC) * 16 + l15;
-            if ((oy < a.Hout) && (ox < a.Wout) && (oz < a.Dout)) {
+            if ((oy < a.wy1) && (ox < a.wx1) && (oz < a.Dout)) {
                 // position in the full output tensor (identity unless this is a phase launch)
                 const int fz = oz * a.os + a.ooz, fy = oy * a.os + a.ooy, fx = ox * a.os + a.oox;
                 const size_t pix_res = (size_t)(C::DIMS == 3 ? fz + a.res_crop : 0) * plane_res +
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             float h = hsum[n];
             h += __shfl_xor(h, 16, 64);
             h += __shfl_xor(h, 32, 64);
-            if (l4 == 0 && oy < a.Hout && ox < a.Wout && oz < a.Dout) {
+            if (l4 == 0 && oy < a.wy1 && ox < a.wx1 && oz < a.Dout) {
                 h += a.head_b;
                 if (a.norm_out) h = h * out_scale + out_shift;
                 a.head_out[(size_t)(oz * a.os + a.ooz) * plane_o + (size_t)(oy * a.os + a.ooy) * a.Wfull + (ox * a.os + a.oox)] = h;

@@ -64,9 +64,9 @@ static const bool g_no_roi = getenv("TPZ_NO_ROI") != nullptr;
 static const bool g_persist = getenv("TPZ_NO_PERSIST") == nullptr;      // persistent workgroups for the large plain conv_split launches
 
 #ifndef TPZ_N_LANES
-#define TPZ_N_LANES 2
+#define TPZ_N_LANES 4
 #endif
-enum { N_LANES = TPZ_N_LANES };      // patch lanes: auxiliary streams the patches / tiles of an image alternate on
+enum { N_LANES = TPZ_N_LANES };      // patch lanes: the most auxiliary streams the patches / tiles of an image alternate on
 enum { NMS_BATCH = 4, NMS_VER = 5, NMS_SNAP = 9, NMS_PICKS = 15, NMS_COUNTERS = 16 };
 
 struct ProfRec {
@@ -109,6 +109,8 @@ struct tpz_ctx {
     hipStream_t lanes_saved_stream = nullptr;
     double* lanes_saved_part = nullptr;
     bool lanes_on = false;
+    int lanes_live = 2;                       // ... of the lanes_begin in progress
+    int n_lanes = 2;                          // lanes in use (<= N_LANES): tpz_ctx_set_lanes(ctx, n), TPZ_LANES
     bool lanes_enabled = !g_no_lanes;         // tpz_ctx_set_lanes
     bool roi_enabled = !g_no_roi;             // tpz_ctx_set_roi: patches compute only what their kept centre depends on
     int persist_mode = g_persist ? 1 : 0;     // tpz_ctx_set_persist: 0 never, 1 large launches (default), 2 every eligible launch
@@ -220,11 +222,12 @@ static int lanes_begin(tpz_ctx* ctx) {
     ctx->lanes_saved_stream = ctx->stream;
     ctx->lanes_saved_part = ctx->d_part;
     ctx->lanes_on = true;
+    ctx->lanes_live = ctx->n_lanes;
     return 0;
 }
 static void lane_enter(tpz_ctx* ctx, int k) {
     if (!ctx->lanes_on) return;
-    tpz_ctx::Lane& ln = ctx->lanes[k % N_LANES];
+    tpz_ctx::Lane& ln = ctx->lanes[k % ctx->lanes_live];
     ctx->stream = ln.stream;
     ctx->pool_cur = &ln.pool;
     ctx->d_part = ln.d_part;
@@ -1040,8 +1043,10 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
 // grid, XCD swizzle and phase stagger of one conv_mfma launch; a.Dout/Hout/Wout, n_chunks, cog_inner are set
 static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int n_cog, double flops) {
     a.xcd_swizzle = 1;
-    a.tiles_x = (a.Wout + ki.TW - 1) / ki.TW;
-    a.tiles_y = (a.Hout + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
+    if (a.wy1 <= 0) { a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout; }      // no window: the whole lattice
+    else flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
+    a.tiles_x = (a.wx1 - a.wx0 + ki.TW - 1) / ki.TW;
+    a.tiles_y = (a.wy1 - a.wy0 + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
     a.tiles_z = ki.dims == 3 ? (a.Dout + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
     a.stagger_first = a.stagger_sleeps = 0;
     // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
@@ -1060,6 +1065,17 @@ static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int 
     prof_end(ctx);
     HIPCHK(ctx, e);
     return 0;
+}
+
+// launch window of an fp32 kernel from the part of the layer's tensor that is needed (`scale` = 2: the half-resolution lattice of
+// a per-parity launch).  The left edge is rounded down to a multiple of 4 pixels: the 16-byte granules of the MFMA kernels'
+// loader stay aligned; the few extra columns are computed like any others.
+static void set_window(ConvArgs& a, const Rect& need, int scale = 1) {
+    if (!need.on) return;
+    a.wy0 = need.y0 / scale; a.wx0 = (need.x0 / scale) & ~3;
+    a.wy1 = std::min(a.Hout, (need.y1 + scale - 1) / scale);
+    a.wx1 = std::min(a.Wout, (need.x1 + scale - 1) / scale);
+    a.wy1 = std::max(a.wy1, a.wy0 + 1); a.wx1 = std::max(a.wx1, a.wx0 + 1);
 }
 
 // conv(cat(upsample2x(s1), s2)) by output parity (prepare_phases): 2^dims plain launches over s1 that write the
@@ -1087,6 +1103,8 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
         a.os = 2; a.oox = px; a.ooy = py; a.ooz = pz;
         a.n_chunks = ph.n_chunks_low;
         a.cog_inner = 1;
+        a.wy0 = a.wx0 = a.wy1 = a.wx1 = 0;
+        if (L.dims == 2) set_window(a, dst.need, 2);
         const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W;
         if (launch_mfma(ctx, *ph.ki_low, a, ph.n_cog_low, fl)) return 1;
     }
@@ -1567,6 +1585,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.slope = L.slope;
     if (L.head) { a.head_out = dst.p; a.out = nullptr; }
     else a.out = dst.p;
+    if (L.dims == 2) set_window(a, dst.need);          // patched denoise: only what the kept centre depends on (need_regions)
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
     if (rt.ki) {
         const ConvKernelInfo& ki = split_out ? *rt.ki_stem_split : *rt.ki;    // same tile and weight packing
@@ -1582,7 +1601,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
         if (launch_mfma(ctx, ki, a, rt.n_cog, flops)) return 1;
     } else {
         if (s1.D != geo.D || s1.H != geo.H || s1.W != geo.W) return fail(ctx, "direct conv cannot upsample");
-        prof_begin(ctx, 1, flops);
+        prof_begin(ctx, 1, a.wy1 > 0 ? flops * (a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout) : flops);
         hipError_t e = launch_conv_direct(a, rt.d_wpk, L.k, L.dims == 3 ? L.k : 1, L.dil, ctx->stream);
         prof_end(ctx);
         HIPCHK(ctx, e);
@@ -1601,8 +1620,8 @@ static int nearest_src_host(int dst, int in_sz, int out_sz) {
     return v < in_sz - 1 ? v : in_sz - 1;
 }
 
-// Which part of every slot's tensor do the pixels `keep` of the program's output depend on?  (2-D programs on the 2xf16
-// kernels.)  A patched denoise keeps only the centre of each patch (denoise.py:299-323: patch_size pixels of a patch_size +
+// Which part of every slot's tensor do the pixels `keep` of the program's output depend on?  (2-D programs, on the 2xf16
+// kernels or -- exact mode -- on the fp32 kernels, whose launches take the same windows: ConvArgs::wy0..wx1.)  A patched denoise keeps only the centre of each patch (denoise.py:299-323: patch_size pixels of a patch_size +
 // 2*padding tile; CLI default 1024 of 2024), and the U-Net's receptive field (~230 pixels) is far smaller than the default
 // padding (500): most of what the full-size layers of a patch compute is thrown away.  Walking the layer list backwards from
 // `keep` -- a conv needs its window grown by the padding, a 2x2 max-pool twice the window, a nearest-upsampled source the
@@ -1610,21 +1629,24 @@ static int nearest_src_host(int dst, int in_sz, int out_sz) {
 // launches cover just that (SplitArgs::wy0..wx1).  Nothing else changes: the tensors keep their full-size layout and
 // coordinates, every kept pixel is computed by the same instructions on the same operands as before (bit-identical output,
 // tests/test_gpu_denoise.py), the statistics of the normalisation are still those of the whole padded patch.
-// Returns an empty vector when the program cannot be windowed (3-D, a layer on an fp32 kernel, an op it does not know).
+// Returns an empty vector when the program cannot be windowed (3-D, a 2xf16 program with a layer left on an fp32 kernel, an op
+// it does not know).
 static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const Rect& keep, bool split) {
     const int nl = (int)m->layers.size();
     std::vector<Rect> need;
-    if (!split || !keep.on || !m->ctx->roi_enabled || nl == 0) return need;
+    if (!keep.on || !m->ctx->roi_enabled || nl == 0) return need;
     // shapes of all slots
     std::vector<int> Hs(m->n_slots, 0), Ws(m->n_slots, 0);
     Hs[0] = H0; Ws[0] = W0;
     for (int i = 0; i < nl; ++i) {
         const LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        if (L.dims != 2 || rt.folded_into >= 0) return need;
+        if (L.dims != 2 || (split && rt.folded_into >= 0)) return need;
         if (L.op == TPZ_OP_CONV) {
+            // (a 2xf16 program with a layer left on an fp32 kernel stays whole: the format conversions between the two read
+            // whole tensors, and what a windowed producer did not write may hold any bit pattern -- the overflow flag)
             const bool windowed = rt.ks || rt.ks_last || (rt.ks_stem && L.src == 0) || (rt.sphase.valid && !rt.sphase.ki_skip_stem);
-            if (!windowed) return need;
+            if (split && !windowed) return need;
             const int g = L.src2 >= 0 ? L.src2 : L.src, span = L.dil * (L.k - 1);
             Hs[L.dst] = Hs[g] + 2 * L.pad - span; Ws[L.dst] = Ws[g] + 2 * L.pad - span;
         } else if (L.op == TPZ_OP_MAXPOOL2) {
@@ -1858,6 +1880,10 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
         }
         if (prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("TPZ_LANES")) {
+        const int n = atoi(e);
+        if (n >= 2 && n <= N_LANES) ctx->n_lanes = n;
+    }
     if (hipStreamCreate(&ctx->own_stream) != hipSuccess) { delete ctx; return fail(nullptr, "hipStreamCreate failed"); }
     ctx->stream = ctx->own_stream;
     if (hipMalloc((void**)&ctx->d_part, 2 * PART_BLOCKS * sizeof(double)) != hipSuccess ||
@@ -2030,7 +2056,9 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
 
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (on < 0 || on > N_LANES) return fail(ctx, "tpz_ctx_set_lanes: 0 (off), 1 (on, two lanes) or a lane count up to %d", (int)N_LANES);
     ctx->lanes_enabled = on != 0;
+    if (on >= 2) ctx->n_lanes = on;
     return 0;
 }
 
@@ -2228,7 +2256,7 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     const int d = patch + 2 * pad;
     const size_t tn = (size_t)d * d * d;
     if (lanes_begin(ctx)) return 1;
-    const int n_lanes = ctx->lanes_on ? N_LANES : 1;
+    const int n_lanes = ctx->lanes_on ? ctx->lanes_live : 1;
     float *tiles[N_LANES] = {}, *touts[N_LANES] = {};
     int rc = 0;
     for (int l = 0; l < n_lanes; ++l) {

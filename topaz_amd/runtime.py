@@ -70,9 +70,9 @@ class Context:
         """pin the fp32 MFMA kernels (no 2xf16 path) for models run on this context"""
         check(self.lib.tpz_ctx_set_exact(self.handle, 1 if on else 0), self.handle)
 
-    def set_lanes(self, on: bool = True) -> None:
-        """patch lanes of tpz_denoise_2d / _3d (two auxiliary streams); off: every launch on the ctx stream"""
-        check(self.lib.tpz_ctx_set_lanes(self.handle, 1 if on else 0), self.handle)
+    def set_lanes(self, on=True) -> None:
+        """patch lanes of tpz_denoise_2d / _3d (two auxiliary streams; an int 2 .. 4: that many); off: every launch on the ctx stream"""
+        check(self.lib.tpz_ctx_set_lanes(self.handle, int(on)), self.handle)
 
     def set_roi(self, on: bool = True) -> None:
         """patch windows of tpz_denoise_2d: each layer of a patch computes only what the kept centre depends on (default on)"""
