@@ -217,10 +217,10 @@ def score(arch: str, sd, x: np.ndarray, num_threads: int = 0, pooling: bool = Fa
 # seeded synthetic weights for architectures whose pretrained blobs are absent: generated by
 # tools/synth_weights.py (pure NumPy); here the ResNet head is calibrated with this oracle's own forward pass
 # ---------------------------------------------------------------------------------------------
-def synthetic_resnet_sd(arch: str, units: int, seed: int, bn: bool = False) -> 'OrderedDict[str, np.ndarray]':
+def synthetic_resnet_sd(arch: str, units: int, seed: int, bn: bool = False, dims: int = 2) -> 'OrderedDict[str, np.ndarray]':
     from tools import synth_weights as sw
-    sd = sw.resnet_sd_uncalibrated(arch, units, seed, bn)
-    return sw.calibrate_head(sd, score(arch, sd, sw.head_probe(seed)))
+    sd = sw.resnet_sd_uncalibrated(arch, units, seed, bn, dims)
+    return sw.calibrate_head(sd, score(arch, sd, sw.head_probe(seed, dims)))
 
 
 def synthetic_basic_sd(sizes, units: int, seed: int, bn: bool = True) -> 'OrderedDict[str, np.ndarray]':

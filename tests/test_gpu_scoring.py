@@ -213,6 +213,36 @@ def test_scoring_3d_vs_reference_golden(gpu_ctx, name):
     assert y.shape == x.shape
     assert np.abs(y - z['y0']).max() <= ATOL
     assert np.abs(y - oscoring.score(str(z['arch']), golden_sd(z), x)).max() <= ATOL
+    # the default path is the plane-stacked 2xf16 one (dilated k^3 convs, 3-D residuals, fused head); the fp32 kernels agree
+    eligible, split_runs, fp32_reruns = m.device_model.split_stats()
+    assert eligible and split_runs == 1 and fp32_reruns == 0
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
+    finally:
+        gpu_ctx.set_exact(False)
+    assert np.abs(y32 - z['y0']).max() <= ATOL
+    assert m.device_model.split_stats()[1] == 1
+
+
+def test_scoring_3d_wide_net_against_float64(gpu_ctx):
+    """a 3-D ResNet8 of 16 units (channels 16 .. 128: the 64- and 128-channel tiles, dilations 1 .. 4, the 5^3 head) on a 32^3
+    volume: 2xf16 vs the float64 oracle next to torch's own fp32 error"""
+    from topaz_amd.model.classifier import LinearClassifier
+    sd = oscoring.synthetic_resnet_sd('resnet8', 16, 11, dims=3)
+    m = LinearClassifier('resnet8', sd)
+    assert m.dims == 3
+    m.eval(); m.fill(); m.cuda()
+    x = np.random.RandomState(5).randn(32, 32, 32).astype(np.float32)
+    ref64 = oscoring.score('resnet8', sd, x, dtype=torch.float64)
+    ref32 = oscoring.score('resnet8', sd, x)
+    y = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
+    eligible, split_runs, fp32_reruns = m.device_model.split_stats()
+    assert eligible and split_runs == 1 and fp32_reruns == 0
+    e_split = float(np.abs(y.astype(np.float64) - ref64).max())
+    e_t32 = float(np.abs(ref32.astype(np.float64) - ref64).max())
+    print(f'resnet8-3d-u16 32^3 vs float64: max |2xf16| {e_split:.2e}  |torch fp32| {e_t32:.2e}')
+    assert e_split <= ATOL and e_split <= 2.0 * max(e_t32, 1e-6)
 
 
 def test_scoring_3d_patches_nms_and_user_pickle(gpu_ctx):

@@ -49,6 +49,17 @@ def main():
     d3 = Denoise3D(DenoiseNet('unet-3d', sw.unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
     t = torch.from_numpy(np.random.RandomState(2000).randn(256, 512, 512).astype(np.float32)).cuda()
     rows.append(('C5 denoise3d unet-3d nf48 (seeded) 512x512x256, 96/48 tiles', timed(lambda: d3.model.device_model.denoise_3d(t, 96, 48), 1), 516.7))
+    # 3-D scoring (`extract --dims 3`): a filled 3-D ResNet8 of 32 units over a 128^3 volume, on the plane-stacked 2xf16 kernels
+    # (default) and on the fp32 kernels
+    sd3 = sw.calibrate_head(sw.resnet_sd_uncalibrated('resnet8', 32, 7, dims=3), (1.0, 0.0))
+    m3 = LinearClassifier('resnet8', sd3)
+    m3.eval(); m3.fill(); m3.cuda()
+    v = torch.from_numpy(np.random.RandomState(3000).randn(128, 128, 128).astype(np.float32)).cuda()
+    tf3 = sum(2.0 * w.size * v.numel() for k, w in sd3.items() if k.endswith('weight') and w.ndim == 5) / 1e12
+    rows.append(('extract --dims 3 resnet8 u32 (seeded) 128^3, 2xf16', timed(lambda: m3(v[None, None])), tf3))
+    ctx.set_exact(True)
+    rows.append(('extract --dims 3 resnet8 u32 (seeded) 128^3, fp32 kernels', timed(lambda: m3(v[None, None])), tf3))
+    ctx.set_exact(False)
     print(f'{"config":<62} {"ms":>10} {"alg. TFLOP":>11} {"TFLOP/s":>9}')
     for name, ms, tf in rows:
         print(f'{name:<62} {ms:10.1f} {tf if tf else float("nan"):11.2f} {(tf / ms * 1e3) if tf else float("nan"):9.1f}')

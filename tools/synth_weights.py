@@ -17,13 +17,13 @@ RESNET_LAYOUT = {
 }
 
 
-def resnet_sd_uncalibrated(arch: str, units: int, seed: int, bn: bool = False) -> 'OrderedDict[str, np.ndarray]':
-    """He-style random weights with the key layout of LinearClassifier(ResNet8/16(units, bn)); unit-scale 1x1 head."""
+def resnet_sd_uncalibrated(arch: str, units: int, seed: int, bn: bool = False, dims: int = 2) -> 'OrderedDict[str, np.ndarray]':
+    """He-style random weights with the key layout of LinearClassifier(ResNet8/16(units, bn, dims)); unit-scale 1x1 head."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
 
     def conv(name, co, ci, k, bias):
-        sd[name + '.weight'] = (rs.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        sd[name + '.weight'] = (rs.randn(*((co, ci) + (k,) * dims)) * np.sqrt(2.0 / (ci * k ** dims))).astype(np.float32)
         if bias:
             sd[name + '.bias'] = (rs.randn(co) * 0.1).astype(np.float32)
 
@@ -53,14 +53,15 @@ def resnet_sd_uncalibrated(arch: str, units: int, seed: int, bn: bool = False) -
             conv(pre + 'conv1', co, ci, 3, not bn)
             if bn:
                 bnorm(pre + 'bn1', co)
-    sd['classifier.weight'] = (rs.randn(1, u[2], 1, 1) * np.sqrt(1.0 / u[2])).astype(np.float32)
+    sd['classifier.weight'] = (rs.randn(*((1, u[2]) + (1,) * dims)) * np.sqrt(1.0 / u[2])).astype(np.float32)
     sd['classifier.bias'] = np.asarray([0.0], dtype=np.float32)
     return sd
 
 
-def head_probe(seed: int) -> np.ndarray:
-    """the 64x64 N(0,1) image whose logits calibrate the head"""
-    return np.random.RandomState(seed + 1).randn(64, 64).astype(np.float32)
+def head_probe(seed: int, dims: int = 2) -> np.ndarray:
+    """the 64x64 (3-D: 32^3) N(0,1) image whose logits calibrate the head"""
+    shape = (64, 64) if dims == 2 else (32, 32, 32)
+    return np.random.RandomState(seed + 1).randn(*shape).astype(np.float32)
 
 
 def calibrate_head(sd, probe_logits):

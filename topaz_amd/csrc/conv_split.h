@@ -534,7 +534,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
 #pragma unroll
             for (int j = 0; j < CCV; ++j) {
                 const unsigned cv = P[4 + j];
-                const int iz = oz + (int)((cv >> 2) & 63u) - pad_z;
+                const int iz = oz + (int)((cv >> 2) & 63u) * D - pad_z;       // (dilated 3-D convs: planes D apart, like the rows)
                 const bool ok = (cv & 1u) && (unsigned)iz < (unsigned)a.Din;
                 coff[j] = (unsigned)((((size_t)(cv >> 8) * a.Din + iz) * a.Hin) * a.Win * 16);
                 cflag[j] = (ok ? 1u : 0u) | (HAS2 ? (cv & 2u) : 0u);
@@ -884,7 +884,8 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const size_t cplane_out = (size_t)a.Dfull * a.Hfull * a.Wfull, cplane_res = (size_t)a.Dres * a.Hres * a.Wres;   // one cell plane
         const size_t plane_out = (size_t)a.cells_out * cplane_out;
         const size_t plane_res = (size_t)a.cells_out * cplane_res;
-        const size_t zoff_out = (size_t)fz * a.Hfull * a.Wfull, zoff_res = (size_t)fz * a.Hres * a.Wres;
+        const size_t zoff_out = (size_t)fz * a.Hfull * a.Wfull;
+        const size_t zoff_res = (size_t)(fz + (a.Dres > 1 ? a.res_crop : 0)) * a.Hres * a.Wres;     // (3-D residuals are cropped in z too)
         const bool has_bias = a.bias != nullptr;
         // Addresses: pixel part (per n, 32-bit cell index inside one cell plane) + cell part (per m, 64-bit) -- one 64-bit
         // add per access.  Invalid pixels and cells are CLAMPED (loads stay in range) and carry a predicate on the store.
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
             float h = hsum[n];
             h += __shfl_xor(h, 16, 64);
             h += __shfl_xor(h, 32, 64);
-            if (l4 == 0 && oy < a.wy1 && ox < a.wx1) a.head_out[(size_t)oy * a.Wout + ox] = h + a.head_b;
+            if (l4 == 0 && oy < a.wy1 && ox < a.wx1) a.head_out[((size_t)oz * a.Hout + oy) * a.Wout + ox] = h + a.head_b;
         }
     } else if constexpr (EPI != EPI_PLAIN_F32) {
         if (__any(big) && lane == 0) atomicOr(a.flag, 1u);

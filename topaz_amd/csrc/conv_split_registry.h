@@ -106,6 +106,10 @@ struct SplitRegistrar {
     TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \
     TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_RES)   \
     TPZ_SPLIT4(K, D, MT, TH, TW, CC, ::tpz::EPI_RES_POST)
+#define TPZ_SPLIT4_RESID_S(K, D, MT, TH, TW, CC, S)        \
+    TPZ_SPLIT4_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_PLAIN) \
+    TPZ_SPLIT4_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_RES)   \
+    TPZ_SPLIT4_S(K, D, MT, TH, TW, CC, S, ::tpz::EPI_RES_POST)
 // ResidA layers: plain (conv0), residual and residual + eval-BN (conv1)
 #define TPZ_SPLIT_RESID(K, D, MT, TH, TW, CC)        \
     TPZ_SPLIT(K, D, MT, TH, TW, CC, ::tpz::EPI_PLAIN) \

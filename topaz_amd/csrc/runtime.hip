@@ -899,7 +899,6 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
             reads[i] = (rt.sphase.valid || rt.ks) ? 1 : 0;
             continue;
         }
-        if (L.dims == 3 && (rt.ki->epi != EPI_PLAIN || L.dil != 1)) continue;      // plane-stacked 3-D: plain convs only
         rt.ks = pick_split(L.k, L.dil, L.cout, rt.ki->epi);
         if (!rt.ks && rt.ki->epi == EPI_PLAIN) rt.ks = pick_split(L.k, L.dil, L.cout, EPI_PLAIN_F32);
         reads[i] = rt.ks ? 1 : 0;
@@ -1187,7 +1186,7 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.n_chunks = rt.s_n_chunks;
     a.cog_inner = L.head ? rt.s_n_cog : 1;
     if (L.dims == 3) {
-        a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = 1; a.ooz = 0;
+        a.KZ = L.k; a.pad_z = L.pad; a.Din = s1.D; a.Dout = dst.D; a.Dfull = dst.D; a.Dres = sres ? sres->D : 1; a.ooz = 0;
     }
     double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * a.Hout * a.Wout;
     if (fold) {
@@ -2022,6 +2021,17 @@ int tpz_model_out_channels(tpz_model* m, int* C) {
     return 0;
 }
 
+// The plane-stacked 3-D kernels address a whole split tensor half with 32-bit byte offsets (conv_split.h fetch): a volume whose
+// widest activation exceeds 4 GiB per half stays on the fp32 kernels.  (No tensor of these networks is larger than the input
+// in voxels: 'same' or valid convolutions, pools.)
+static bool split_volume_fits(const tpz_model* m, int D, int H, int W) {
+    if (D <= 1) return true;
+    size_t cmax = 1;
+    for (const LayerRT& rt : m->layers)
+        if (rt.L.op == TPZ_OP_CONV) cmax = std::max(cmax, (size_t)std::max(rt.L.cin, rt.L.cout));
+    return split_cells((int)cmax) * (size_t)D * H * W * 16 < ((size_t)1 << 32) - 16;
+}
+
 int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out) {
     if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_model_forward: NULL argument");
     tpz_ctx* ctx = m->ctx;
@@ -2034,7 +2044,7 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
     for (int b = 0; b < n; ++b) {
         float* out_b = d_out + (size_t)b * Co * Do * Ho * Wo;
         bool done = false;
-        if (m->split_ok && !ctx->exact) {
+        if (m->split_ok && !ctx->exact && split_volume_fits(m, D, H, W)) {
             // 2xf16 path; an activation beyond the f16 range (flag) sends this image to the fp32 kernels instead
             HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
             std::vector<Slot> slots(m->n_slots);
