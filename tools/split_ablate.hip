@@ -70,6 +70,7 @@ int bench(const char* name, int cin, int cout, int H) {
     a.post_scale = vec; a.post_shift = vec; a.head_w = vec; a.head_out = out; a.zeros = zeros; a.flag = flag;
     a.cells_in = a.cells_in1 = (int)cells_in; a.Hin = a.H1 = H; a.Win = a.W1 = H; a.Cout = cout; a.cells_out = (int)cells_out; a.Hout = Ho; a.Wout = Ho;
     a.os = 1; a.Hfull = Ho; a.Wfull = Ho; a.Hres = Ho; a.Wres = Ho; a.n_chunks = n_chunks; a.xcd_swizzle = 1;
+    a.KZ = 1; a.Din = a.Dout = a.Dfull = a.Dres = 1;     // a 2-D launch, as launch_split fills it in
     a.wy0 = a.wx0 = 0; a.wy1 = Ho; a.wx1 = Ho;          // the whole lattice
     a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;
@@ -162,6 +163,7 @@ int quick(const char* name, int cin, int cout, int H) {
     a.post_scale = vec; a.post_shift = vec; a.head_w = vec; a.head_out = out; a.zeros = zeros; a.flag = flag;
     a.cells_in = a.cells_in1 = (int)cells_in; a.Hin = a.H1 = H; a.Win = a.W1 = H; a.Cout = cout; a.cells_out = (int)cells_out; a.Hout = Ho; a.Wout = Ho;
     a.os = 1; a.Hfull = Ho; a.Wfull = Ho; a.Hres = Ho; a.Wres = Ho; a.n_chunks = n_chunks; a.xcd_swizzle = 1;
+    a.KZ = 1; a.Din = a.Dout = a.Dfull = a.Dres = 1;     // a 2-D launch, as launch_split fills it in
     a.wy0 = a.wx0 = 0; a.wy1 = Ho; a.wx1 = Ho;          // the whole lattice
     a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;

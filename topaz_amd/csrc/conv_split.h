@@ -887,9 +887,13 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const size_t zoff_out = (size_t)fz * a.Hfull * a.Wfull;
         const size_t zoff_res = (size_t)(fz + (a.Dres > 1 ? a.res_crop : 0)) * a.Hres * a.Wres;     // (3-D residuals are cropped in z too)
         const bool has_bias = a.bias != nullptr;
-        // Addresses: pixel part (per n, 32-bit cell index inside one cell plane) + cell part (per m, 64-bit) -- one 64-bit
-        // add per access.  Invalid pixels and cells are CLAMPED (loads stay in range) and carry a predicate on the store.
-        unsigned opix[NW], rpix[NW];
+        // Addresses of the split cells (stores, residual loads): buffer accesses.  Per fragment m one descriptor per plane (hi / lo),
+        // built from scalars, covers the fragment's two cells from this tile's output plane on (num_records counts only the cells
+        // that exist: the second cell of an odd cell count, padding fragments fall out of range); per pixel fragment n one 32-bit
+        // byte offset per lane = pixel + (second cell of the fragment) + (second half of the cell), OOB for the pixels outside
+        // the launch window -- no 64-bit lane arithmetic, no predicate: the hardware drops what is out of range (stores) or
+        // returns zeros (loads).  (round 2: 2 x v_lshl_add_u64 + exec masking per access; the epilogue is issue-bound.)
+        unsigned opix[NW], rpix[NW], ovo[NW], rvo[NW];
         bool okv[NW];
         if constexpr (EPI != EPI_HEAD) {       // (the fused head stores nothing here: every pixel just accumulates)
 #pragma unroll
@@ -907,8 +911,17 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     // the even row / even column of each 2x2 window stores its maximum (floor: a window must be whole)
                     okv[n] = (l15 & 1) == 0 && oy < a.wy1 && ox < a.wx1 && oy + 1 < a.Hout && ox + 1 < a.Wout;
                 }
+                const unsigned lane_o = (unsigned)(l4 >> 1) * (unsigned)(cplane_out * 16) + (unsigned)(l4 & 1) * 8u;
+                const unsigned lane_r = (unsigned)(l4 >> 1) * (unsigned)(cplane_res * 16) + (unsigned)(l4 & 1) * 8u;
+                ovo[n] = okv[n] ? opix[n] * 16u + lane_o : OOB;
+                rvo[n] = rpix[n] * 16u + lane_r;              // (clamped pixel: in range whenever its cell exists)
             }
         }
+        const unsigned cp16_o = (unsigned)(cplane_out * 16), cp16_r = (unsigned)(cplane_res * 16);       // bytes of one cell plane
+        const unsigned zo16 = (unsigned)(zoff_out * 16), zr16 = (unsigned)(zoff_res * 16);                // ... to this tile's plane
+        const size_t pl16_o = plane_out * 16, pl16_r = plane_res * 16;                                    // hi -> lo
+        const unsigned char* const out8 = reinterpret_cast<const unsigned char*>(a.out);
+        const unsigned char* const res8 = reinterpret_cast<const unsigned char*>(a.res);
         const float slope = a.slope;
         u16x2 bigacc = {0, 0};                 // running maximum of |hi| bit patterns: >= 0x7c00 <=> an inf / NaN half
         // ... of the pixels that are stored only: a tile may overhang the launch window, and what lies outside a producer's
@@ -916,19 +929,53 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         unsigned okmask[NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) okmask[n] = (EPI != EPI_HEAD && okv[n]) ? 0x7fff7fffu : 0u;
+        // where channel fragment m lies (all wave-uniform): its first channel cb within the parity (sy, sx) of a sub-pixel
+        // layer, its cells cell0 (lanes l4 = 0, 1) and cell0 + 1 (l4 = 2, 3), how many of the two exist
+        struct Frag { int cb, sy, sx, cell0, ncell; bool ok; };
+        auto frag_of = [&](int m) {
+            Frag f;
+            const int covb = cog * C::MT + m * 16;
+            f.cb = covb; f.sy = 0; f.sx = 0; f.ok = true;
+            if (a.subpix_cout > 0) {                               // Cout % 16 == 0: one parity per fragment
+                const int par = covb / a.subpix_cout;
+                f.cb = covb - par * a.subpix_cout;
+                f.sx = par & 1; f.sy = (par >> 1) & 1;
+                f.ok = par <= 3;                                   // (padding fragments of the last co-group)
+            }
+            f.cell0 = f.cb >> 3;
+            const int nc = f.ok ? a.cells_out - f.cell0 : 0;
+            f.ncell = nc < 0 ? 0 : nc > 2 ? 2 : nc;
+            return f;
+        };
+        // the residual cells of fragment m (all NW pixel fragments, hi and lo) are requested one fragment AHEAD of their use:
+        // the latency of these loads, not the arithmetic, bounded the residual epilogues.  (The compiler cannot hoist them
+        // itself: res and out may be the same tensor -- the in-place skip launch of a per-parity layer -- where every lane
+        // reads exactly the cells it writes later, so running ahead of the stores of OTHER fragments is safe.)
+        constexpr bool RESID = (EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32);
+        u32x2 rhb[2][NW], rlb[2][NW];
+        auto load_res = [&](int m, u32x2 (&rh)[NW], u32x2 (&rl)[NW]) {
+            const Frag f = frag_of(m);
+            const unsigned ex16 = zr16 + (unsigned)(f.sy * a.Wres + f.sx) * 16u;
+            const unsigned nrec = f.ncell > 0 ? (unsigned)f.ncell * cp16_r - ex16 : 0u;
+            const unsigned char* rb8 = res8 + ((size_t)((unsigned)f.cell0 * (unsigned long long)cp16_r) + ex16);
+            const __amdgpu_buffer_rsrc_t srd_rh = make_srd(rb8, nrec);
+            const __amdgpu_buffer_rsrc_t srd_rl = make_srd(rb8 + pl16_r, nrec);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                rh[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rh, (int)rvo[n], 0, 0);
+                rl[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rl, (int)rvo[n], 0, 0);
+            }
+        };
+        if constexpr (RESID) load_res(0, rhb[0], rlb[0]);
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-            const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // 4 consecutive (virtual) channels: half a cell
-            int co0 = cov0, sy = 0, sx = 0;
-            if (a.subpix_cout > 0) {                               // Cout % 16 == 0: one parity per fragment
-                const int par = cov0 / a.subpix_cout;
-                co0 = cov0 - par * a.subpix_cout;
-                sx = par & 1; sy = (par >> 1) & 1;
-                if (par > 3) co0 = a.Cout;                         // padding fragments of the last co-group
-            }
-            const int cell = co0 >> 3, half = (co0 >> 2) & 1;
-            const bool cell_ok = cell < a.cells_out;
-            const int cellc = cell_ok ? cell : a.cells_out - 1;
+            const Frag f = frag_of(m);
+            const int cov0 = cog * C::MT + m * 16 + l4 * 4;       // this lane's 4 consecutive (virtual) channels: half a cell
+            const int sy = f.sy, sx = f.sx, cell0 = f.cell0, ncell = f.ncell;
+            const int co0 = f.ok ? f.cb + l4 * 4 : a.Cout;
+            if constexpr (RESID) { if (m + 1 < MW) load_res(m + 1, rhb[(m + 1) & 1], rlb[(m + 1) & 1]); }
+            u32x2 (&rh)[NW] = rhb[m & 1];
+            u32x2 (&rl)[NW] = rlb[m & 1];
             // per-channel constants: one float4 each.  Every array is zero-padded to whole tiles, so the channels that pad
             // the last cell come out as 0 * acc + 0 = 0 without a mask (their residual cells hold zeros as well)
             // (kept as channel PAIRS: the arithmetic below is written on two-wide vectors -> v_pk_fma / v_pk_mul / v_pk_add)
@@ -951,17 +998,15 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 }
             }
             const f32x2 slope2 = {slope, slope};
-            // this lane's half cell of plane `cell` at pixel 0 (+ the sub-pixel parity shift): hi plane; lo = + plane_out
-            uint2* const ob = reinterpret_cast<uint2*>(a.out + ((size_t)cellc * cplane_out + zoff_out + (unsigned)(sy * a.Wfull + sx))) + half;
-            uint2 rh[NW], rl[NW];
-            if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32)) {
-                const uint2* const rb = reinterpret_cast<const uint2*>(a.res + ((size_t)cellc * cplane_res + zoff_res + (unsigned)(sy * a.Wres + sx))) + half;
-#pragma unroll
-                for (int n = 0; n < NW; ++n) {
-                    const uint2* rp = rb + 2 * (size_t)rpix[n];
-                    rh[n] = rp[0];
-                    rl[n] = rp[plane_res * 2];
-                }
+            // descriptors of the fragment's cells from this tile's plane (+ the sub-pixel parity shift) on: hi plane, lo = + plane_out.
+            // 32-bit scalar arithmetic but for the final pointer (the host keeps two cell planes below 4 GiB)
+            __amdgpu_buffer_rsrc_t srd_oh, srd_ol;
+            if constexpr (EPI != EPI_HEAD && EPI != EPI_PLAIN_F32) {
+                const unsigned ex16 = zo16 + (unsigned)(sy * a.Wfull + sx) * 16u;
+                const unsigned nrec = ncell > 0 ? (unsigned)ncell * cp16_o - ex16 : 0u;
+                const unsigned char* ob8 = out8 + ((size_t)((unsigned)cell0 * (unsigned long long)cp16_o) + ex16);
+                srd_oh = make_srd(ob8, nrec);
+                srd_ol = make_srd(ob8 + pl16_o, nrec);
             }
             if constexpr (EPI == EPI_POOL) {
                 static_assert(EPI != EPI_POOL || (C::RPW % 2 == 0 && C::D == 1), "pooling pairs tile rows inside a wave");
@@ -978,16 +1023,14 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                         const f32x2 t = __builtin_elementwise_max(t0, t1);                       // rows y, y + 1
                         v[h] = __builtin_elementwise_max(t, (f32x2){__shfl_xor(t[0], 1, 64), __shfl_xor(t[1], 1, 64)});   // columns x, x + 1
                     }
-                    if (okv[n] && cell_ok) {
-                        uint2 hi, lo;
-                        split2(v[0], hi.x, lo.x);
-                        split2(v[1], hi.y, lo.y);
-                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & okmask[n]));
-                        bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & okmask[n]));
-                        uint2* op = ob + 2 * (size_t)opix[n];
-                        op[0] = hi;
-                        op[plane_out * 2] = lo;
-                    }
+                    unsigned h0, l0, h1, l1;
+                    split2m(v[0], h0, l0);
+                    split2m(v[1], h1, l1);
+                    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h0 & okmask[n]));
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h1 & okmask[n]));
+                    __builtin_amdgcn_raw_buffer_store_b64(hi, srd_oh, (int)ovo[n], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, srd_ol, (int)ovo[n], 0, 0);
                 }
                 continue;
             }
@@ -996,9 +1039,12 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 f32x2 v[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    v[h] = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + bi[h];
-                    if constexpr ((EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32))
-                        v[h] += h ? join2(rh[n].y, rl[n].y) : join2(rh[n].x, rl[n].x);
+                    // acc * scale + (bias + residual): the residual's halves enter through v_fma_mix_f32 (no conversions), the
+                    // FMA comes last (an inline-asm result in front of the max would be canonicalised first: v_max x, x)
+                    f32x2 addend = bi[h];
+                    if constexpr (RESID)
+                        addend = add_halves(add_halves(addend, h ? rl[n].y : rl[n].x), h ? rh[n].y : rh[n].x);   // (bias + lo) + hi
+                    v[h] = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + addend;
                     if constexpr (EPI == EPI_RES_POST) v[h] = v[h] * psc[h] + psh[h];
                     v[h] = __builtin_elementwise_max(v[h], v[h] * slope2);   // v > 0 ? v : v * slope for every slope <= 1 (host: no others here)
                     if constexpr (EPI == EPI_HEAD) v[h] *= hw[h];
@@ -1014,20 +1060,14 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     for (int r = 0; r < 4; ++r)
                         if (okv[n] && co0 + r < a.Cout) fb[r * cs] = v[r >> 1][r & 1];
                 } else {
-                    // (everything but the two stores outside the predicate: a long predicated block gets a skip branch, and
-                    // at every branch target the compiler waits for ALL outstanding memory operations -- the previous
-                    // fragment's stores included)
-                    uint2 hi, lo;
-                    split2(v[0], hi.x, lo.x);
-                    split2(v[1], hi.y, lo.y);
-                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.x & okmask[n]));
-                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, hi.y & okmask[n]));
-                    uint2* op = ob + 2 * (size_t)opix[n];
-                    asm volatile("" : "+v"(lo.x), "+v"(lo.y));     // (keeps the lo arithmetic from being sunk into the predicated block)
-                    if (okv[n] && cell_ok) {
-                        op[0] = hi;
-                        op[plane_out * 2] = lo;
-                    }
+                    unsigned h0, l0, h1, l1;
+                    split2m(v[0], h0, l0);
+                    split2m(v[1], h1, l1);
+                    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h0 & okmask[n]));
+                    bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h1 & okmask[n]));
+                    __builtin_amdgcn_raw_buffer_store_b64(hi, srd_oh, (int)ovo[n], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(lo, srd_ol, (int)ovo[n], 0, 0);
                 }
             }
         }

@@ -1247,6 +1247,10 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
         return fail(ctx, "3-D tensor too large for the plane-stacked 2xf16 kernel (tile the volume)");
     if ((size_t)ks.CC * std::max((size_t)a.Hin * a.Win, (size_t)a.H1 * a.W1) * 16 >= ((size_t)1 << 32) - 16)
         return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
+    // ... and so are the epilogue's buffer offsets: the two cell planes of a channel fragment, of the output and of the residual
+    if (ks.epi != EPI_HEAD && ks.epi != EPI_PLAIN_F32 &&
+        2 * std::max((size_t)a.Dfull * a.Hfull * a.Wfull, (size_t)a.Dres * a.Hres * a.Wres) * 16 >= ((size_t)1 << 32) - 16)
+        return fail(ctx, "tensor too large for one launch (%d x %d x %d): process it in patches", a.Dfull, a.Hfull, a.Wfull);
     dim3 grid(a.tiles_x, a.tiles_y, (unsigned)gz);
     bool next_ok = false;
     a.plan = split_plan(ctx, ks, a, &next_ok);

@@ -50,5 +50,24 @@ __device__ __forceinline__ void split2(f32x2 v, unsigned& hi, unsigned& lo) {
 __device__ __forceinline__ f32x2 join2(unsigned hi, unsigned lo) {
     return __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2) + __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
 }
+// ... with the mixed-precision FMAs of gfx950 (v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16 read an f16 half of a register as
+// an fp32 operand, the latter two round the fp32 result to f16 into one half of the destination): no v_cvt_f32_f16 in front of the
+// arithmetic.  Bit-identical to split2 (v - (float)hi is exact in fp32, so there is one rounding, to f16, either way); checked
+// against the conversions on the MI355X by tools/mix_probe.hip.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2m(f32x2 v, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v[1]));
+    lo = l;
+}
+// c + (float2)(the two f16 halves of h): two v_fma_mix_f32
+__device__ __forceinline__ f32x2 add_halves(f32x2 c, unsigned h) {
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(c[0]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(c[1]));
+    return (f32x2){d0, d1};
+}
 
 }  // namespace tpz
