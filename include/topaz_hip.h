@@ -73,7 +73,11 @@ typedef struct tpz_layer {
 } tpz_layer;
 
 /* ---- context ------------------------------------------------------------------------- */
-/* replaces topaz/cuda.py:16-32 set_device (no CPU fallback: errors are reported, never hidden) */
+/* replaces topaz/cuda.py:16-32 set_device (no CPU fallback: errors are reported, never hidden).
+ * Threading: a context, with the models loaded into it, is driven by ONE host thread at a time -- the staging ring is the
+ * exception: its producer side (the h2d call and the pinned buffers) may run on a reader thread, as the CLI does.  One
+ * process per GPU with one ctx is the tested configuration (topaz --gpus N); several contexts on one device driven by
+ * several threads at once are not. */
 int tpz_ctx_create(int device_id, tpz_ctx** out);
 void tpz_ctx_destroy(tpz_ctx* ctx);
 const char* tpz_last_error(tpz_ctx* ctx);            /* ctx may be NULL: last global error */

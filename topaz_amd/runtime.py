@@ -14,22 +14,7 @@ import torch
 from . import _lib
 from ._lib import TpzLayer, check, load_library
 
-import threading
-
 _contexts = {}
-_tls = threading.local()
-
-
-def set_lane(lane: int) -> None:
-    """Lanes are independent execution contexts on one GPU (own tpz_ctx: HIP stream, workspace pool,
-    scratch).  A host thread that calls set_lane(k) gets lane k's context from get_context(); with one
-    lane per thread two micrographs can be in flight and one's under-filled launches and host syncs
-    (NMS counter reads) overlap the other's convolutions."""
-    _tls.lane = int(lane)
-
-
-def get_lane() -> int:
-    return getattr(_tls, 'lane', 0)
 
 
 class Context:
@@ -130,7 +115,7 @@ Context.prof_kernels_bytes = _prof_kernels_bytes
 def get_context(device: Optional[int] = None) -> Context:
     if device is None or device < 0:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    key = (device, get_lane())
+    key = device
     ctx = _contexts.get(key)
     if ctx is None:
         ctx = Context(device)
