@@ -95,7 +95,11 @@ void tpz_model_free(tpz_model* m);
 
 /* replaces model(x) -- LinearClassifier.forward (classifier.py:48-66), UDenoiseNet.forward
  * (denoising/models.py:130-175), UDenoiseNet3D.forward (:515-562).
- * d_in [n][1][D][H][W] -> d_out [n][1][Do][Ho][Wo]; D = 1 for 2-D models. */
+ * d_in [n][1][D][H][W] -> d_out [n][1][Do][Ho][Wo]; D = 1 for 2-D models.
+ * Arithmetic path per image: the 2xf16 kernels where the model has them, re-run on the fp32 kernels when an activation left
+ * the f16 range; a 3-D volume whose widest activation exceeds 4 GiB per split half (32-bit offsets of the plane-stacked
+ * kernels: e.g. 128 channels x more than 256^3 voxels) goes to the fp32 kernels directly -- or is tiled by the caller, as
+ * classify_patches does.  A 2-D image above ~11 500^2 pixels is refused with a message: process it in patches. */
 int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out);
 /* output size of the model for a given input size */
 int tpz_model_out_shape(tpz_model* m, int D, int H, int W, int* Do, int* Ho, int* Wo);

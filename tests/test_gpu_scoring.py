@@ -245,6 +245,31 @@ def test_scoring_3d_wide_net_against_float64(gpu_ctx):
     assert e_split <= ATOL and e_split <= 2.0 * max(e_t32, 1e-6)
 
 
+def test_scoring_3d_volume_beyond_32bit_offsets_stays_on_fp32(gpu_ctx):
+    """the plane-stacked 2xf16 kernels address one half of a split tensor with 32-bit byte offsets: a volume whose widest
+    activation (128 channels = 16 cells here) would exceed 4 GiB per half -- more than 256^3 voxels -- is scored on the
+    fp32 kernels instead of failing (runtime.hip split_volume_fits); one voxel fewer per plane and it takes the 2xf16 path"""
+    from topaz_amd.model.classifier import LinearClassifier
+    from tools import synth_weights as sw
+    sd = sw.calibrate_head(sw.resnet_sd_uncalibrated('resnet8', 32, 3, dims=3), (1.0, 0.0))
+    m = LinearClassifier('resnet8', sd)
+    m.eval(); m.fill(); m.cuda()
+    big = torch.from_numpy(np.random.RandomState(9).randn(258, 256, 256).astype(np.float32)).cuda()
+    y = m(big[None, None])[0, 0]
+    eligible, split_runs, fp32_reruns = m.device_model.split_stats()
+    assert eligible and split_runs == 0 and fp32_reruns == 0          # never tried: not an overflow re-run
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = m(big[None, None])[0, 0]
+    finally:
+        gpu_ctx.set_exact(False)
+    assert torch.equal(y, y32) and bool(torch.isfinite(y).all())
+    del y, y32, big
+    small = torch.from_numpy(np.random.RandomState(9).randn(64, 256, 256).astype(np.float32)).cuda()
+    m(small[None, None])
+    assert m.device_model.split_stats()[1] == 1
+
+
 def test_scoring_3d_patches_nms_and_user_pickle(gpu_ctx):
     """classify_patches (PatchDataset tiles, zero-filled halo) vs the reference's output; the 3-D pick table of the
     reference's own score map; a full-module pickle of a 3-D classifier loads and scores like the reference did"""
