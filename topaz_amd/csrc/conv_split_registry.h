@@ -22,15 +22,19 @@ struct SplitKernelInfo {
 void register_split(const SplitKernelInfo& info);
 const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
-// three instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
+// four instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
 // persistent workgroups that prefetch their next tile (MODE 4; a.n_tiles > 0 selects it, the grid is then (workgroups, 1, 1);
-// not for the fused head) and the general one (second source and / or plane-stacked 3-D)
+// not for the fused head), the 2-D one with a second source (MODE 1) and the general one (plane-stacked 3-D, with or without
+// a second source: MODE 3)
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -51,6 +55,10 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
         }
     } else if (plain) {
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    } else if (a.KZ <= 1 && a.Din <= 1) {
+        // a second source in 2-D (fused upsample + concat, sub-pixel skip cell, folded projection): without the plane-stacked
+        // addressing the K loop is 290 - 390 instructions instead of 520 - 630
+        hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 1>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     } else {
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     }
