@@ -22,10 +22,11 @@ struct SplitKernelInfo {
 void register_split(const SplitKernelInfo& info);
 const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
-// four instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
+// five instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
 // persistent workgroups that prefetch their next tile (MODE 4; a.n_tiles > 0 selects it, the grid is then (workgroups, 1, 1);
-// not for the fused head), the 2-D one with a second source (MODE 1) and the general one (plane-stacked 3-D, with or without
-// a second source: MODE 3)
+// not for the fused head), 2-D with a second source (MODE 1), plane-stacked 3-D with one source (MODE 2) and with two
+// (MODE 3).  It is the COMBINATION of the last two that is expensive per step (lanes of one DMA round may straddle cells of
+// both tensors): 520 - 630 instructions in the K-loop body against 260 - 390 in the others.
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
@@ -34,6 +35,9 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 3>),
@@ -59,6 +63,9 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
         // a second source in 2-D (fused upsample + concat, sub-pixel skip cell, folded projection): without the plane-stacked
         // addressing the K loop is 290 - 390 instructions instead of 520 - 630
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 1>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    } else if (!a.in2) {
+        // plane-stacked 3-D, one source (most layers of the 3-D U-Net, every layer of the 3-D scoring networks)
+        hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 2>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     } else {
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     }
