@@ -93,6 +93,8 @@ struct SplitArgs {
     int cog_inner;            // co-groups looped inside the kernel (fused head), else 1
     int tiles_x, tiles_y;
     int n_tiles;              // persistent launches (MODE 4): tiles_x * tiles_y * grid-z slices, walked by gridDim.x workgroups
+    int vol_srcmajor;         // plane-stacked 3-D with two sources: virtual cells ordered source-major (all planes of `in`, then all
+                              // planes of `in2`) -- no chunk mixes the two tensors (MODE 11); 0: plane-major (MODE 3)
     int xcd_swizzle;
     // output WINDOW of the launch, in its own lattice coordinates: the tiles cover [wy0, wy1) x [wx0, wx1) only and nothing
     // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
@@ -218,7 +220,7 @@ struct SplitCfg {
 
 // What a plan depends on (besides the kernel configuration): the K loop's cells and sources, nothing of the tile or image size
 struct SplitPlanKey {
-    int cells_in, cells_in1, n_chunks, has_in2, vol, KZ, fold_cells, fold_tap;
+    int cells_in, cells_in1, n_chunks, has_in2, vol, KZ, fold_cells, fold_tap, srcmajor;
 };
 
 // Host: the schedule of one tile's K loop (SplitStep) for configuration C.  Entry 0 = the fetch of chunk 0 (all rounds, issued
@@ -247,12 +249,24 @@ void split_make_plan(const SplitPlanKey& k, std::vector<SplitStep>& out) {
             const int have = k.cells_in - pf * C::CC;
             if (have < C::CC) e.dma |= (uint32_t)(have > 1 ? have : 1) << SPLIT_DMA_NCELL_SHIFT;     // (a chunk that exists has >= 1 cell)
         } else {
+            bool any2 = false, any1 = false;
             for (int j = 0; j < C::CC && j < 4; ++j) {
-                const int v = pf * C::CC + j, kz = v / k.cells_in, c = v - kz * k.cells_in;
+                const int v = pf * C::CC + j;
+                int kz, c;                     // plane and cell (counted over both sources) of virtual cell v
+                if (!k.srcmajor) {
+                    kz = v / k.cells_in; c = v - kz * k.cells_in;
+                } else if (v < k.KZ * k.cells_in1) {
+                    kz = v / k.cells_in1; c = v - kz * k.cells_in1;
+                } else {
+                    const int vv = v - k.KZ * k.cells_in1, c2n = k.cells_in - k.cells_in1;
+                    kz = vv / c2n; c = k.cells_in1 + (vv - kz * c2n);
+                }
                 if (kz >= k.KZ) { e.cell[j] = 0; continue; }
                 const bool l2 = c >= k.cells_in1;
+                (l2 ? any2 : any1) = true;
                 e.cell[j] = 1u | (l2 ? 2u : 0u) | (uint32_t)kz << 2 | (uint32_t)(l2 ? c - k.cells_in1 : c) << 8;
             }
+            if (k.srcmajor && any2 && !any1) e.dma |= SPLIT_DMA_SRC2;      // (the host orders source-major only when no chunk mixes)
         }
     };
     out.assign((size_t)n_stages + 1, SplitStep{});
@@ -370,6 +384,10 @@ template <class C, int EPI, int ABL = 0, int MODE = 3>
 __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     constexpr bool HAS2 = (MODE & 1) != 0, VOLM = (MODE & 2) != 0;
+    // MODE bit 3 (with bits 0 and 1): every chunk of a plane-stacked two-source launch comes from ONE tensor (SplitArgs::
+    // vol_srcmajor) -- the source is a scalar choice per chunk, as in 2-D, instead of a per-lane one
+    constexpr bool UNI2 = (MODE & 8) != 0;
+    static_assert(!UNI2 || (HAS2 && VOLM), "MODE 11 = two sources, plane-stacked, chunk-uniform");
     // MODE bit 2: PERSISTENT workgroups.  The grid is a few workgroups per CU; each walks its share of the tiles (XCD-aware
     // order) and, during the last chunk of a tile's K loop, fetches the first chunk and the first weight stage of ITS NEXT tile
     // (the plan's SPLIT_DMA_NEXT entries): the table computation, the first fetch and its full memory latency -- 6 - 9 k cycles
@@ -525,10 +543,10 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
         const bool second = HAS2 && (d & SPLIT_DMA_SRC2) != 0;
         const unsigned ncell = (d >> SPLIT_DMA_NCELL_SHIFT) & 7u;       // 0: every cell of the chunk exists
         const uint4* chunk = second ? in2 + (size_t)P[3] * (C::CC * hw2) : a.in + (size_t)P[3] * (C::CC * (size_t)a.H1 * a.W1);
-        const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? a.in : chunk));
-        const size_t lo_delta0 = (second ? plane2 : plane1) * 16;       // bytes from a hi cell to its lo cell
+        const unsigned char* bhi = reinterpret_cast<const unsigned char*>(uniform_ptr(vol ? ((UNI2 && second) ? in2 : a.in) : chunk));
+        const size_t lo_delta0 = ((second && (!vol || UNI2)) ? plane2 : plane1) * 16;       // bytes from a hi cell to its lo cell
         // buffer descriptors: the chunk's CC cell planes (2-D) or one half of the whole tensor (plane-stacked 3-D), hi and lo
-        const size_t ext = vol ? plane1 * 16 : (second ? (size_t)C::CC * hw2 : (size_t)C::CC * a.H1 * a.W1) * 16;
+        const size_t ext = vol ? ((UNI2 && second) ? plane2 : plane1) * 16 : (second ? (size_t)C::CC * hw2 : (size_t)C::CC * a.H1 * a.W1) * 16;
         const __amdgpu_buffer_rsrc_t srd_hi = make_srd(bhi, ext), srd_lo = make_srd(bhi + lo_delta0, ext);
         // plane-stacked 3-D: virtual cell v = kz * cells + c of the chunk is cell c of input plane oz + kz - pad_z, of `in` or
         // `in2` (32-bit byte offsets from the tensor start: the host keeps plane-stacked tensors below 4 GiB per half)
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                 const int iz = oz + (int)((cv >> 2) & 63u) * D - pad_z;       // (dilated 3-D convs: planes D apart, like the rows)
                 const bool ok = (cv & 1u) && (unsigned)iz < (unsigned)a.Din;
                 coff[j] = (unsigned)((((size_t)(cv >> 8) * a.Din + iz) * a.Hin) * a.Win * 16);
-                cflag[j] = (ok ? 1u : 0u) | (HAS2 ? (cv & 2u) : 0u);
+                cflag[j] = (ok ? 1u : 0u) | ((HAS2 && !UNI2) ? (cv & 2u) : 0u);
             }
         }
 #pragma unroll
@@ -560,11 +578,11 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
                     for (int j = 1; j < CCV; ++j)
                         if (g >= j * C::CELL_STRIDE) { co = coff[j]; cf = cflag[j]; }
                     if (!(cf & 1u)) off = OOB;
-                    else if (off != OOB) { off += co; lane2 = HAS2 && (cf & 2u) != 0; }
+                    else if (off != OOB) { off += co; lane2 = HAS2 && !UNI2 && (cf & 2u) != 0; }
                 }
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
                 if constexpr (BUFDMA) {
-                    if (VOLM && HAS2 && __any(lane2)) {
+                    if (VOLM && HAS2 && !UNI2 && __any(lane2)) {
                         // (plane-stacked 3-D with a second source: the lanes of a wave may straddle cells of both tensors)
                         if (lane2) {
                             const __amdgpu_buffer_rsrc_t s2h = make_srd(in2, plane2 * 16), s2l = make_srd(in2 + plane2, plane2 * 16);

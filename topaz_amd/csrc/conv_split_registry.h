@@ -22,10 +22,10 @@ struct SplitKernelInfo {
 void register_split(const SplitKernelInfo& info);
 const SplitKernelInfo* find_split(int K, int D, int MT, int epi, int KX = 0, int sps = 0);    // KX = 0: square (KX == K); sps = 0: any
 
-// five instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
+// six instantiations per configuration: the plain single-source 2-D conv (MODE 0: lean scalar code), the same with
 // persistent workgroups that prefetch their next tile (MODE 4; a.n_tiles > 0 selects it, the grid is then (workgroups, 1, 1);
-// not for the fused head), 2-D with a second source (MODE 1), plane-stacked 3-D with one source (MODE 2) and with two
-// (MODE 3).  It is the COMBINATION of the last two that is expensive per step (lanes of one DMA round may straddle cells of
+// not for the fused head), 2-D with a second source (MODE 1), plane-stacked 3-D with one source (MODE 2), with two whose
+// chunks never mix (MODE 11: source-major cell order) and with two in general (MODE 3).  It is the COMBINATION of the last two that is expensive per step (lanes of one DMA round may straddle cells of
 // both tensors): 520 - 630 instructions in the K-loop body against 260 - 390 in the others.
 template <class C, int EPI>
 hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
@@ -38,6 +38,9 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 11>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C, EPI, 0, 3>),
@@ -66,6 +69,9 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     } else if (!a.in2) {
         // plane-stacked 3-D, one source (most layers of the 3-D U-Net, every layer of the 3-D scoring networks)
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 2>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
+    } else if (a.vol_srcmajor) {
+        // plane-stacked 3-D, two sources, no chunk mixes them (the 3-D sub-pixel decoder with its space-to-depth skip cell)
+        hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 11>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     } else {
         hipLaunchKernelGGL((conv_split_kernel<C, EPI, 0, 3>), grid, dim3(C::THREADS), C::LDS_BYTES, s, a);
     }

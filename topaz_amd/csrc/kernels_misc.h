@@ -17,6 +17,7 @@ hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, 
                              hipStream_t s);
 hipError_t launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t s);
 hipError_t launch_maxpool2_split(const void* in, void* out, int C, int D, int H, int W, int dims, hipStream_t s);
+hipError_t launch_maxpoolz_split(const float* in, float* out, int C, int D, int H, int W, hipStream_t s);   // z pairs only (split cells)
 hipError_t launch_maxpoolk(const void* in, void* out, int C, int D, int H, int W, int k, int dil, int dims, bool split,
                            hipStream_t s);
 hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_t rows, int W, int Wo, unsigned* flag,

@@ -202,6 +202,39 @@ __global__ __launch_bounds__(256) void maxpool2_split_kernel(const uint4* __rest
     }
 }
 
+// The z half of MaxPool3d(2) on split cells: out[c][z] = max(in[c][2z], in[c][2z + 1]) plane-wise.  The in-plane half ran in
+// the producing conv's epilogue (EPI_POOL on the plane-stacked kernels, which see one output plane at a time): the conv then
+// writes a quarter of its tensor and this kernel reads that quarter instead of all of it.
+__global__ __launch_bounds__(256) void maxpoolz_split_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int cells,
+                                                             int D, int Do, size_t hw) {
+    const size_t n = (size_t)cells * Do * hw, plane_in = (size_t)cells * D * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t px = i % hw, t = i / hw;
+        const int z = (int)(t % Do);
+        const size_t c = t / Do;
+        const size_t p = (c * D + 2 * z) * hw + px, q = p + hw;
+        f16x8 bh = __builtin_bit_cast(f16x8, in[p]), bl = __builtin_bit_cast(f16x8, in[plane_in + p]);
+        const f16x8 h = __builtin_bit_cast(f16x8, in[q]), l = __builtin_bit_cast(f16x8, in[plane_in + q]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)bh[j] + (float)bl[j], b = (float)h[j] + (float)l[j];
+            if (b > a || a != a) { bh[j] = h[j]; bl[j] = l[j]; }       // (as maxpool2_split_kernel)
+        }
+        out[i] = __builtin_bit_cast(uint4, bh);
+        out[n + i] = __builtin_bit_cast(uint4, bl);
+    }
+}
+
+hipError_t launch_maxpoolz_split(const float* in, float* out, int C, int D, int H, int W, hipStream_t s) {
+    const int Do = D / 2;
+    const size_t n = split_cells(C) * (size_t)Do * H * W;
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpoolz_split_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, (uint4*)out, (int)split_cells(C), D,
+                       Do, (size_t)H * W);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // Dilated k^dims max over a window, stride 1, no padding: the FILLED form of MaxPool(3, stride = 2) in the ResNets trained
 // with --pooling max and in ResNet6 (resnet.py:10-47: fill() turns the stride into a dilation of everything downstream and

@@ -342,6 +342,7 @@ struct LayerRT {
         int n_cog_sub = 1;
         bool sub_with_skip = false;            // ... the 1-channel skip source folded in as 4 space-to-depth channels
         bool low_with_skip = false;            // 3x3(x3): the same fold into the per-parity kernels (one more cell)
+        bool srcmajor = false;                 // ... in 3-D with the virtual cells ordered source-major (conv_split.h MODE 11)
         const SplitKernelInfo* ks_low_plain = nullptr;
         void* d_w_low = nullptr;               // the packs of all parities, w_phase_bytes apart
         float* d_ws_low = nullptr;             // [parity][cout]
@@ -703,8 +704,10 @@ static thread_local std::vector<float> g_inv_tmp;
 
 // kz_n > 1: 3-D weights [cout][cin][kz][k][k] are laid out for the plane-stacked 2-D kernel (conv_split.h): the
 // input channels of plane kz become channels [kz*cells*8, ...) of a 2-D conv with kz_n * cells * 8 input channels
+// c1_major > 0 (a multiple of 8; two-source 3-D launches, SplitArgs::vol_srcmajor): the channels [0, c1_major) of every plane
+// come first, then the remaining ones of every plane -- the order split_make_plan walks when srcmajor is set
 static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInfo& ks, const float* w, int cout, int cin,
-                                int* n_cog, int* n_chunks, void** d_w, float** d_ws, int kz_n = 1) {
+                                int* n_cog, int* n_chunks, void** d_w, float** d_ws, int kz_n = 1, int c1_major = 0) {
     std::vector<float> stacked;
     if (kz_n > 1) {
         const int c8 = (int)split_cells(cin) * 8, k = ks.K;
@@ -712,9 +715,14 @@ static int upload_split_weights(tpz_ctx* ctx, tpz_model* m, const SplitKernelInf
         stacked.assign((size_t)cout * kz_n * c8 * taps2, 0.f);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                for (int kz = 0; kz < kz_n; ++kz)
-                    memcpy(&stacked[((size_t)co * kz_n * c8 + (size_t)kz * c8 + ci) * taps2],
+                for (int kz = 0; kz < kz_n; ++kz) {
+                    size_t vch = (size_t)kz * c8 + ci;                                  // plane-major
+                    if (c1_major > 0)
+                        vch = ci < c1_major ? (size_t)kz * c1_major + ci
+                                            : (size_t)kz_n * c1_major + (size_t)kz * (c8 - c1_major) + (ci - c1_major);
+                    memcpy(&stacked[((size_t)co * kz_n * c8 + vch) * taps2],
                            &w[(((size_t)co * cin + ci) * kz_n + kz) * taps2], taps2 * sizeof(float));
+                }
         w = stacked.data();
         cin = kz_n * c8;
     }
@@ -801,8 +809,12 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
                 }
         }
         if (!sp.low_with_skip) sub_w.insert(sub_w.end(), eff.begin(), eff.end());          // [parity][cout][c1][taps1]
+        // 3-D with the skip cell: source-major cell order whenever the first source's planes fill whole chunks (then no chunk of
+        // the K loop mixes the two tensors: conv_split.h MODE 11)
+        static const bool no_srcmajor = getenv("TPZ_NO_SRCMAJOR") != nullptr;   // A/B switch
+        sp.srcmajor = dims == 3 && sp.low_with_skip && !no_srcmajor && (k1z_n * (c1 / 8)) % sp.ks_low_plain->CC == 0;
         if (upload_split_weights(ctx, m, sp.low_with_skip ? *sp.ks_low_plain : *sp.ks_low, eff.data(), L.cout, c1e,
-                                 &sp.n_cog_low, &sp.n_chunks_low, nullptr, nullptr, k1z_n)) return 1;
+                                 &sp.n_cog_low, &sp.n_chunks_low, nullptr, nullptr, k1z_n, sp.srcmajor ? c1 : 0)) return 1;
         sp.w_phase_bytes = g_pack_tmp.size() * sizeof(uint16_t);
         all_w.insert(all_w.end(), g_pack_tmp.begin(), g_pack_tmp.end());
         g_inv_tmp.resize(chan_pad(L.cout), 0.f);                      // stride chan_pad(cout) per parity
@@ -976,7 +988,9 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
     for (int i = 0; i + 1 < nl; ++i) {
         LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        if (L.op != TPZ_OP_CONV || L.dims != 2 || L.dil != 1 || L.head || L.res >= 0 || L.post_scale_off >= 0) continue;
+        // (3-D: the plane-stacked kernels pool in-plane, maxpoolz_split_kernel finishes the z pairs)
+        static const bool no_pool3d = getenv("TPZ_NO_POOL3D") != nullptr;       // A/B switch
+        if (L.op != TPZ_OP_CONV || L.dil != 1 || L.head || L.res >= 0 || L.post_scale_off >= 0 || (L.dims == 3 && no_pool3d)) continue;
         const SplitKernelInfo* base = rt.ks_stem ? rt.ks_stem : ((rt.ks && L.src2 < 0 && rt.ks->epi == EPI_PLAIN) ? rt.ks : nullptr);
         if (!base) continue;
         int readers = 0, pool = -1;
@@ -1213,6 +1227,7 @@ static const SplitStep* split_plan(tpz_ctx* ctx, const SplitKernelInfo& ks, cons
     memset(&k, 0, sizeof k);
     k.cells_in = a.cells_in; k.cells_in1 = a.cells_in1; k.n_chunks = a.n_chunks; k.has_in2 = a.in2 != nullptr;
     k.vol = (a.KZ > 1 || a.Din > 1) ? 1 : 0; k.KZ = a.KZ; k.fold_cells = a.fold_cells; k.fold_tap = a.fold_tap;
+    k.srcmajor = (k.vol && a.in2) ? a.vol_srcmajor : 0;
     for (auto& e : ctx->split_plans)
         if (e.ks == &ks && memcmp(&e.key, &k, sizeof k) == 0) { *next_ok = e.next_ok; return e.d; }
     std::vector<SplitStep> h;
@@ -1419,6 +1434,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
             a.cells_in = a.cells_in1 + 1;
             a.res = nullptr;
             a.bias = rt.d_bias;
+            a.vol_srcmajor = sp.srcmajor ? 1 : 0;
         }
         a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
         a.Cout = L.cout; a.cells_out = (int)split_cells(L.cout);
@@ -1791,6 +1807,21 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             else if (use_split) rc = run_conv_split(ctx, rt, v1, sres ? &vres : nullptr, dst, s2 ? &v2 : nullptr, fuse_pool);
             else rc = run_conv(ctx, rt, v1, s2 ? &v2 : nullptr, sres ? &vres : nullptr, dst, d_nrm,
                                (d_nrm && i == nl - 1) ? 1 : 0, stem_split);
+        } else if (L.op == TPZ_OP_MAXPOOL2 && s1.pooled && L.dims == 3) {
+            // pooled in-plane by the producing conv: the z pairs remain
+            const int Do = s1.D / 2;
+            if (Do < 1) { rc = fail(ctx, "layer %d: input too small to pool", i); break; }
+            float* p = (i == nl - 1) ? d_out : (float*)pool_alloc(ctx, split_cells(s1.C) * 8 * (size_t)Do * s1.H * s1.W * sizeof(float));
+            if (!p) { rc = fail(ctx, "out of device memory (layer %d)", i); break; }
+            const Slot src = s1;
+            set_dense(dst, p, src.C, Do, src.H, src.W);
+            dst.split = true;
+            dst.alt = nullptr;
+            dst.owned = (i != nl - 1);
+            prof_begin(ctx, 2, 0);
+            hipError_t e = launch_maxpoolz_split(src.p, dst.p, src.C, src.D, src.H, src.W, ctx->stream);
+            prof_end(ctx);
+            if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else if (L.op == TPZ_OP_MAXPOOL2 && s1.pooled) {
             // already pooled by the producing conv: the slot changes hands
             dst = s1;
