@@ -114,6 +114,25 @@ def test_unet3d_nf48_tile_vs_oracle(gpu_ctx):
     assert _err(d.denoise(t, 32, 16, verbose=False), ref) <= ATOL
 
 
+def test_unet3d_odd_sizes_whole_volume(gpu_ctx):
+    """odd extents in every axis through the whole 3-D U-Net (floor pooling five times, nearest upsampling back onto odd
+    skip tensors): the in-plane max-pool fused into the plane-stacked convs, the z-pair kernel and the fused / per-parity
+    decoder paths against the oracle, default path and fp32 kernels"""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)
+    d = Denoise3D(DenoiseNet('unet-3d', sd))
+    for shape, seed in (((41, 50, 37), 5), ((33, 35, 63), 6)):
+        v = (np.random.RandomState(seed).randn(*shape) * 1.5 - 0.5).astype(np.float32)
+        ref = oden.denoise3d(sd, v, -1, 0)
+        assert _err(d.denoise(v, -1, verbose=False), ref) <= ATOL, shape
+        gpu_ctx.set_exact(True)
+        try:
+            assert _err(d.denoise(v, -1, verbose=False), ref) <= ATOL, shape
+        finally:
+            gpu_ctx.set_exact(False)
+
+
 def test_full_size_4096_default_patching_vs_oracle_patch(gpu_ctx):
     """BASELINE size with the CLI-default patching (-s 1024 -p 500): the output inside one patch's centre must
     equal the oracle's _denoise of that patch crop alone (patches are independent, denoise.py:307-322)."""
