@@ -224,6 +224,180 @@ def pcie_inclusive(models, host_imgs, args, dev, n=4):
                     'pick table copied back to the host; file I/O excluded'}
 
 
+class GpuSampler:
+    """Shader clock and socket power of THIS rank's GPU while the timed region runs, from the amdgpu hwmon files of the DRM card
+    with the HIP device's PCI address (freq1_input: sclk in Hz; power1_input / power1_average: microwatts), sampled by a thread
+    every 25 ms: the boxes of the pool sustain different clocks under the f16-MFMA load (7 % spread of the step time,
+    profiles/r03_bench_boxes.txt), so a slow box can be told from a regression.  Fields are null where the files do not exist."""
+
+    def __init__(self, index: int = 0):
+        import glob
+        self.sclk, self.power = [], []
+        self._stop = False
+        self._thread = None
+        self.dev, self.fq, self.pw = None, None, None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = f'{int(getattr(pr, "pci_domain_id", 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0'
+        except (AttributeError, RuntimeError, AssertionError):
+            bdf = None
+        for d in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+            if bdf and os.path.basename(os.path.realpath(d)) == bdf:
+                self.dev = d
+        if self.dev:
+            for name in ('freq1_input',):
+                hits = glob.glob(os.path.join(self.dev, 'hwmon', 'hwmon*', name))
+                self.fq = hits[0] if hits else None
+            for name in ('power1_input', 'power1_average'):
+                hits = glob.glob(os.path.join(self.dev, 'hwmon', 'hwmon*', name))
+                if hits:
+                    self.pw = hits[0]
+                    break
+
+    def _read(self):
+        for path, out, unit in ((self.fq, self.sclk, 1e6), (self.pw, self.power, 1e6)):
+            if path:
+                try:
+                    out.append(float(open(path).read()) / unit)
+                except (OSError, ValueError):
+                    pass
+
+    def _run(self):
+        while not self._stop:
+            self._read()
+            time.sleep(0.025)
+
+    def __enter__(self):
+        if self.fq or self.pw:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread:
+            self._thread.join()
+
+    def summary(self):
+        mean = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {'sclk_mhz_mean': mean(self.sclk), 'sclk_mhz_min': min(self.sclk) if self.sclk else None,
+                'power_w_mean': mean(self.power), 'power_w_max': max(self.power) if self.power else None,
+                'samples': max(len(self.sclk), len(self.power)),
+                'source': (f'{self.dev}/hwmon (freq1_input, power1_input)' if self.dev else 'no DRM card with the HIP device\'s PCI address') +
+                          ', 25 ms sampling during the timed region'}
+
+
+# the reference's own layer FLOP (2 * Cout * Cin * k^dims * output pixels, every patch / tile in full) of the BASELINE configs
+CONFIG_TFLOP = {'c2_extract_resnet8_u64': 44.23, 'c2_extract_resnet8_u32': 11.09, 'c3_denoise_unet_patched': 29.06,
+                'c3_denoise_unet_whole': 9.68, 'c5_denoise3d_unet3d': 516.7}
+
+
+def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
+    """BASELINE.json configs 2, 3 and 5 one by one, after the timed region: ms per unit (best of two after
+    one warm-up), the reference's algorithmic TFLOP, the executed TFLOP (what the launches really compute: patch windows,
+    per-parity decoders), executed TFLOP/s against the 2xf16 ceiling of 833, launches, and the oracle on a bounded sample of
+    the same config on this host."""
+    from oracle import denoising as oden
+    from oracle import nms as onms
+    from oracle import scoring as oscoring
+    from tools import synth_weights as sw
+    from topaz_amd import runtime as rt
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    from topaz_amd.model.factory import load_model
+    x = imgs[0]
+    S = args.size
+    out = {}
+
+    def measure(key, fn, n=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        best = None
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); torch.cuda.synchronize(dev)
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        ctx.prof_enable(1); ctx.prof_reset()
+        l0 = ctx.launches()
+        fn()
+        torch.cuda.synchronize(dev)
+        launches = ctx.launches() - l0
+        _, _, fl = ctx.prof_get(0)
+        ctx.prof_enable(False)
+        out[key] = {'ms': 1e3 * best, 'algorithmic_tflop': CONFIG_TFLOP[key], 'executed_tflop': fl / 1e12,
+                    'executed_tflops': fl / best / 1e12, 'frac': fl / best / 1e12 / SPLIT_PEAK_TFLOPS,
+                    'reference_tflops': CONFIG_TFLOP[key] / best, 'conv_and_elementwise_launches': launches}
+        return out[key]
+
+    def scorer(m):
+        return lambda: rt.nms(m(x[None, None])[0, 0], args.radius, args.threshold)
+
+    u32 = load_model('resnet8_u32')
+    u32.eval(); u32.fill(); u32.cuda()
+    m64 = models['score'][0] if 'score' in models else sw.hip_resnet('resnet8', 64, seed=7)[0]
+    sd64 = models['score'][1] if 'score' in models else None
+    dn = models['denoise'][0] if 'denoise' in models else None
+    measure('c2_extract_resnet8_u64', scorer(m64))
+    measure('c2_extract_resnet8_u32', scorer(u32))
+    if dn is not None:
+        measure('c3_denoise_unet_patched', lambda: dn.denoise_device(x, args.patch_size, args.patch_padding))
+        measure('c3_denoise_unet_whole', lambda: dn.denoise_device(x, -1, 0))
+    if dn is not None:
+        # (not a BASELINE config: the pretrained fully convolutional denoiser, 11x11 64->64 body -- VERDICT r03 item 6)
+        from topaz_amd.denoise import Denoise
+        CONFIG_TFLOP['denoise_fcnn_patched'] = 17.15 * 50.4 / 16.8
+        fc = Denoise('fcnn')
+        measure('denoise_fcnn_patched', lambda: fc.denoise_device(x, args.patch_size, args.patch_padding))
+        out['denoise_fcnn_patched']['unit'] = f'one {S}x{S} micrograph, -s {args.patch_size} -p {args.patch_padding}'
+    sd3 = sw.unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)
+    d3 = Denoise3D(DenoiseNet('unet-3d', sd3))
+    tomo = torch.randn(256, 512, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(2000))
+    measure('c5_denoise3d_unet3d', lambda: d3.model.device_model.denoise_3d(tomo, 96, 48), n=1)
+    out['c5_denoise3d_unet3d']['unit'] = 'one 512x512x256 tomogram, 96/48 tiles (108 tiles of 192^3)'
+    del tomo
+    for k in ('c2_extract_resnet8_u64', 'c2_extract_resnet8_u32', 'c3_denoise_unet_patched', 'c3_denoise_unet_whole'):
+        if k in out:
+            out[k]['unit'] = f'one {S}x{S} micrograph'
+    if with_cpu:
+        # the oracle on a bounded sample of each config, scaled by the pixels / voxels the whole unit pushes through the net
+        P = 1024
+        crop = np.random.RandomState(1000).randn(P, P).astype(np.float32)
+        full_px = float(S) * S
+
+        def cpu(key, seconds, scale, sample):
+            if key in out:
+                out[key]['cpu_baseline'] = {'ms': 1e3 * seconds * scale, 'kind': 'port', 'cores': torch.get_num_threads(),
+                                            'sample': sample, 'gpu_over_cpu': seconds * scale / (out[key]['ms'] * 1e-3)}
+        sdu = {k: v.numpy() for k, v in u32.state_dict().items()}
+        oscoring.score('resnet8', sdu, crop[:256, :256].copy())
+        t0 = time.time(); lg = oscoring.score('resnet8', sdu, crop); onms.nms2d(lg, args.radius, args.threshold); t = time.time() - t0
+        cpu('c2_extract_resnet8_u32', t, full_px / (P * P), f'{P}x{P} crop through the oracle scorer + C NMS, scaled by pixels')
+        if sd64 is not None:
+            t0 = time.time(); lg = oscoring.score('resnet8', sd64, crop); onms.nms2d(lg, args.radius, args.threshold); t = time.time() - t0
+            cpu('c2_extract_resnet8_u64', t, full_px / (P * P), f'{P}x{P} crop through the oracle scorer + C NMS, scaled by pixels')
+        if dn is not None:
+            sd = models['denoise'][1]
+            oden.denoise('unet', sd, crop[:256, :256].copy(), -1)
+            t0 = time.time(); oden.denoise('unet', sd, crop, -1); t = time.time() - t0
+            n_px = 0
+            for i in range(0, S, args.patch_size):
+                for j in range(0, S, args.patch_size):
+                    n_px += ((min(S, i + args.patch_size + args.patch_padding) - max(0, i - args.patch_padding)) *
+                             (min(S, j + args.patch_size + args.patch_padding) - max(0, j - args.patch_padding)))
+            cpu('c3_denoise_unet_patched', t, n_px / float(P * P), f'{P}x{P} crop through the oracle U-Net, scaled to the '
+                f'{n_px} pixels of the 16 padded patches the reference computes')
+            cpu('c3_denoise_unet_whole', t, full_px / (P * P), f'{P}x{P} crop through the oracle U-Net, scaled by pixels')
+        T = 96
+        vol = torch.from_numpy(np.random.RandomState(2000).randn(T, T, T).astype(np.float32))
+        tsd3 = oden.to_torch_sd(sd3)
+        oden.denoise_whole('unet-3d', tsd3, vol[:32, :32, :32].clone())
+        t0 = time.time(); oden.denoise_whole('unet-3d', tsd3, vol); t = time.time() - t0
+        cpu('c5_denoise3d_unet3d', t, 108.0 * 192 ** 3 / float(T ** 3), f'one {T}^3 tile through the oracle 3-D U-Net, scaled to the '
+            '108 tiles of 192^3 voxels the reference computes')
+    return out
+
+
 def timed_steps(models, imgs, args, dev, n):
     """n steps bracketed by device synchronisation; returns (seconds, pick tables)"""
     torch.cuda.synchronize(dev)
@@ -249,6 +423,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the exact_fp32 and pcie_inclusive legs')
+    ap.add_argument('--no-configs', action='store_true', help='skip the per-config legs (BASELINE configs 2, 3, 5 one by one)')
     ap.add_argument('--exact-steps', type=int, default=3)
     ap.add_argument('--dry-run', action='store_true', help='CPU-only plumbing check over gloo (no hot path, not a measurement)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
@@ -295,10 +470,15 @@ def main():
     # ---- the timed region: barrier + synchronize on both sides, exactly K steps, then the one exchange step
     torch.cuda.synchronize(dev)
     parallel.barrier(dev)
+    launches0 = ctx.launches()
+    sampler = GpuSampler(local_rank)
+    sampler.__enter__()                                  # (joined after the timed region: its 25 ms sleep is not part of the job)
     t0 = time.perf_counter()
     picks = [run_step(models, imgs[i % n_res], args) for i in range(args.steps)]
     torch.cuda.synchronize(dev)
     t_compute = time.perf_counter() - t0
+    sampler._stop = True
+    launches_per_step = (ctx.launches() - launches0) / max(1, args.steps)
     ids = [rank + i * world for i in range(args.steps)]
     scs, cds = [p[0] for p in picks], [p[1] for p in picks]
     have_picks = cds[0] is not None
@@ -310,6 +490,7 @@ def main():
     dt = time.perf_counter() - t0
     # every rank's own compute time per micrograph: stragglers (host contention between the ranks' launch threads, a slow
     # device) show as a spread between min and max
+    sampler.__exit__()
     rank_ms = parallel.gather_scalars(1e3 * t_compute / max(1, args.steps), dev)
     total_steps = int(parallel.sum_over_ranks(float(args.steps), dev))
     dt = parallel.max_over_ranks(dt, dev)
@@ -416,7 +597,32 @@ def main():
                                         'projections and the last conv run as layers of their own here (not fused / folded)',
                                 'like_for_like_with': 'value'}
         extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
+        if args.workload != 'denoise':
+            # A/B of the patch raster of the 8-wave launches (scoring stage): row-major XCD runs instead of 8 x 4 blocks of tiles
+            ctx.set_raster(False)
+            try:
+                run_step(models, imgs[0], args)
+                t, _ = timed_steps(models, imgs, args, dev, 2)
+            finally:
+                ctx.set_raster(True)
+            extras['row_major_raster'] = {'value': 2 / t, 'ms_per_step': 1e3 * t / 2, 'steps': 2, 'unit': 'micrographs/s',
+                                          'note': 'tpz_ctx_set_raster(0): each XCD walks a row-major run of tiles (the round-3 order)'}
         if args.workload != 'extract':
+            # A/B of the batched patches: the same step with the patches of the denoise stage launched one by one, alternating
+            # on the two patch lanes (the round-3 form)
+            ctx.set_batch(0)
+            try:
+                run_step(models, imgs[0], args)
+                l0 = ctx.launches()
+                t, _ = timed_steps(models, imgs, args, dev, 2)
+                l1 = ctx.launches()
+            finally:
+                ctx.set_batch(8)
+            extras['patch_lanes_unbatched'] = {
+                'value': 2 / t, 'ms_per_step': 1e3 * t / 2, 'steps': 2, 'unit': 'micrographs/s', 'launches_per_step': (l1 - l0) / 2,
+                'note': 'tpz_ctx_set_batch(0): every patch of the denoise stage launches its own layers (two patch lanes); `value` '
+                        'above issues the same layer of 8 patches as one grid -- bit-identical output '
+                        '(tests/test_gpu_denoise.py::test_batched_patches_are_bit_identical)'}
             # A/B of the patch windows: the same step with every tensor of every denoise patch computed in full
             ctx.set_roi(False)
             try:
@@ -430,6 +636,16 @@ def main():
                         'reference does, although only the 1024^2 centre of a patch is kept; `value` above computes, per '
                         'layer, only the rectangle those kept pixels depend on -- bit-identical output '
                         '(tests/test_gpu_denoise.py::test_patch_windows_are_bit_identical)'}
+
+    # images the 2xf16 path sent back to the fp32 kernels (an activation beyond the f16 range): 0 on this workload
+    fp32_reruns = 0
+    for key in ('denoise', 'score'):
+        if key in models:
+            dm = models[key][0].model.device_model if key == 'denoise' else models[key][0].device_model
+            fp32_reruns += int(dm.split_stats()[2])
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs and args.workload == 'pipeline':
+        configs = baseline_configs(ctx, models, imgs, args, dev, with_cpu=not args.no_cpu_baseline)
 
     if rank == 0:
         out = {
@@ -463,6 +679,9 @@ def main():
                                  '(bit-identical to computing the 2024^2 tensors in full; full_patch_tensors = the A/B leg)',
             },
             'gather_ms': 1e3 * t_gather,
+            'launches_per_step': launches_per_step,
+            'fp32_reruns': fp32_reruns,
+            'gpu_clock_power': sampler.summary(),
             # the dominant kernel = the conv instantiation with the most time in a step (live HIP-event timing of the
             # timed steps' own launches); `achieved` is algorithmic (fp32-equivalent) FLOP/s
             'roofline': {
@@ -490,6 +709,8 @@ def main():
             },
             **extras,
         }
+        if configs is not None:
+            out['configs'] = configs
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(models, args)
         print(json.dumps(out))

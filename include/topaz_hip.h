@@ -208,18 +208,35 @@ int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float*
  * 3x3 / 5x5 layers, folded 1x1 projections, fused head), the 2-D U-Nets / FCNN (encoders with fused max-pool, per-parity and
  * sub-pixel decoders, the 1-output-channel last conv as a column kernel) and the 3-D U-Net (plane-stacked) -- runs by default on
  * the f16 matrix cores with every fp32 operand carried as two f16 halves and three exact products accumulated in fp32
- * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  3-D scoring networks and layers with
- * a PReLU slope > 1 stay on the fp32-MFMA kernels.  An activation beyond the f16 range is detected on the device and that
+ * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  The rule per layer: it takes the 2xf16
+ * path when a conv_split kernel exists for its shape (2-D and plane-stacked 3-D alike: the 3-D scoring networks run there too),
+ * otherwise it stays on its fp32-MFMA kernel; layers with a PReLU slope > 1 always do.  An activation beyond the f16 range is detected on the device and that
  * image is re-run on the fp32 kernels, so results never depend on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1
  * in the environment) pins the fp32 kernels.
  * tpz_model_split_stats: whether the model is eligible, images finished on the 2xf16 path, images re-run in fp32. */
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
+/* Range scaling of the scoring pass (tpz_model_forward of a program that ends in the linear head), on by default
+ * (TPZ_NO_RANGE=1 / on = 0: off).  `topaz extract` scores micrographs as they come (topaz/extract.py:234-249 does not normalise), and
+ * a raw-count image (mean 10^3 .. 10^4) would leave the f16 range in the very first layer and send the whole image to the fp32
+ * kernels.  A scoring network is positively homogeneous in (input, biases) jointly -- convolutions, PReLU / ReLU, max-pools,
+ * residual adds, eval-BN affines, the linear head --, so it is run on x * 2^-s with every bias-like vector scaled by 2^-s and its
+ * logits multiplied by 2^s: exact (powers of two).  s >= 0 is the smallest exponent with max|x| * 2^-s <= 32, found on the device
+ * (no host round trip); an image within +-32 runs unchanged (s = 0), bit for bit. */
+int tpz_ctx_set_range(tpz_ctx* ctx, int on);
 /* Patch lanes: tpz_denoise_2d / _3d enqueue the independent patches / tiles of an image alternately on two auxiliary
  * streams (own workspace each), so that one patch's small, latency-bound launches run under its neighbour's large ones.
  * On by default (TPZ_NO_LANES=1 in the environment or on = 0 here: everything on the ctx stream, e.g. to time kernels in
  * isolation).  on = 2 .. 4 (or TPZ_LANES=n): that many lanes; more than two measured no gain on the 4096^2 pipeline
  * (profiles/r03_lanes.txt).  Results are bit-identical either way. */
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
+/* Batched patches (2xf16 path): tpz_denoise_2d / _3d record the launches of up to n (<= 8) independent patches / tiles and issue
+ * them layer by layer, the same layer of all n as ONE grid (conv_split_multi_kernel): the deep levels of a U-Net are 16-tile
+ * launches on a 256-CU chip, ~400 of them per micrograph (denoise.py:299-323 runs the patches one after another).  Default n = 8
+ * (TPZ_BATCH=n, TPZ_NO_BATCH=1 in the environment); n = 0: off -- the patches then alternate on the patch lanes above, as do the
+ * fp32 kernels (exact mode, overflow re-run) always.  Results are bit-identical either way.
+ * tpz_prof_launches: kernel launches the library has issued on this context (convolutions, elementwise, NMS sweeps excluded). */
+int tpz_ctx_set_batch(tpz_ctx* ctx, int n);
+long long tpz_prof_launches(tpz_ctx* ctx);
 /* Patch windows: a patch of tpz_denoise_2d keeps only its centre (topaz/denoise.py:299-323: patch_size pixels of a
  * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the
  * U-Net's receptive field is ~230 pixels, the CLI's default padding 500).  The statistics of the normalisation are still the
@@ -232,7 +249,22 @@ int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
  * (default), 2: every eligible launch, with `workgroups` of them (0: one grid slot each) -- the form the tests use to run
  * small images through many tiles per workgroup.  Results are bit-identical in every mode. */
 int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups);
+/* Patch raster of the large 8-wave launches (conv_split.h, xcd_swizzle 2): the 32 tiles an XCD's CUs hold at a time form an
+ * 8 x 4 block of neighbouring tiles (rows taken phase-major for dilated layers), so that their halos overlap in that XCD's L2,
+ * instead of a row-major run that shares columns only.  On by default (TPZ_NO_RASTER=1 / on = 0: row-major runs).  Same
+ * arithmetic per tile: results are bit-identical. */
+int tpz_ctx_set_raster(tpz_ctx* ctx, int on);
+/* Internal tiling of tpz_model_forward: a 2-D image of more than limit_px pixels (default 40 Mi: beyond a 6400^2 frame) through a
+ * size-preserving scoring network is scored in tile x tile tiles (default 4096), each computed on the tile grown by the network's
+ * receptive halo and stitched -- where the reference scores any image that fits memory (topaz/extract.py:247-249), the kernels
+ * address 32-bit byte offsets per chunk of cells (< ~11 500^2 pixels) and a whole-image pass would hold every activation at full
+ * size (an 11 520 x 8 184 super-resolution frame: 146 GB).  Bit-identical to the whole-image pass. */
+int tpz_ctx_set_tiling(tpz_ctx* ctx, long long limit_px, int tile);
 int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, long long* fp32_reruns);
+/* Coverage of the 2xf16 path: convolution layers of the model, how many of them have a 2xf16 kernel, and the others as text
+ * ("#layer KxK dD cin->cout, ...").  `eligible` above is true as soon as ONE layer has: the rest of a mixed program runs on its
+ * fp32 kernels (correct, converted either side, several times slower) -- topaz_amd warns once per model when that happens. */
+int tpz_model_split_layers(tpz_model* m, int* n_conv, int* n_split, char* off_path, int off_path_len);
 /* One 2-D convolution on the 2xf16 kernels with fp32 [C][H][W] tensors at the boundary (converted on the device):
  * unit-test / interop entry; arguments as tpz_conv (single source).  *overflow = 1 when a result left the f16 range. */
 int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, const float* h_w, const float* h_b,

@@ -269,3 +269,13 @@ def test_denoiser_pickles_dispatch_on_the_class_name(tmp_path):
         load_model(saved['DenoiseNet'])
     with pytest.raises(NotImplementedError, match='UDenoiseNetX'):
         load_model(saved['UDenoiseNetX'])
+
+
+def test_particle_pixel_count_keeps_the_reference_cube_quirk():
+    """topaz/stats.py:17-26 builds its mask on a CUBE of side 2r + 1 whatever `dims` is: in 2-D the disc is counted once per
+    z plane.  Values below computed with the reference's own formula (np.meshgrid over three axes)."""
+    from topaz_amd.stats import calculate_pi, pixels_given_radius
+    want = {(1, 2): 15, (1, 3): 7, (3, 2): 203, (3, 3): 123, (7, 2): 2235, (7, 3): 1419, (14, 2): 17777, (14, 3): 11513}
+    for (r, d), n in want.items():
+        assert pixels_given_radius(r, dims=d) == n, (r, d)
+    assert abs(calculate_pi(300, 14, 4096 * 4096) - 17777 * 300 / 4096 ** 2) < 1e-12

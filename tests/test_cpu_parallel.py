@@ -6,6 +6,8 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -147,43 +149,52 @@ def test_launch_local_ranks_propagates_failure():
 
 
 def test_launcher_reads_stdin_once_for_all_ranks(monkeypatch):
-    """`topaz extract --gpus N` with the micrograph list on stdin: the launcher reads stdin ONCE and hands
-    every rank the whole list through an @file argument; rank processes get no stdin.  (N ranks sharing one pipe would each
-    read a part of it, take that part for the whole list and shard it again: most micrographs silently never processed.)"""
+    """`topaz extract --gpus N` with the micrograph list on stdin: the launcher reads stdin ONCE and hands every rank the whole
+    list OUT OF BAND (a file named in TOPAZ_AMD_INPUT_LIST); rank processes get no stdin and an unchanged command line.  (N ranks
+    sharing one pipe would each read a part of it, take that part for the whole list and shard it again; an @file token would be
+    re-parsed by the ranks: names starting with '-' or '@', or a trailing variadic option, would be misread.)"""
     import io
     import sys
     from topaz_amd import main as tmain
     from topaz_amd import parallel
     seen = {}
 
-    def fake_launch(n, cmd, **kw):
+    def fake_launch(n, cmd, env=None, **kw):
         seen['n'] = n
         seen['cmd'] = list(cmd)
-        lists = [a for a in cmd if a.startswith('@')]
-        assert len(lists) == 1
-        seen['names'] = open(lists[0][1:]).read().split()
+        seen['list'] = env['TOPAZ_AMD_INPUT_LIST']
+        seen['names'] = open(seen['list']).read().split('\n')[:-1]
         return 0
 
     monkeypatch.setattr(parallel, 'launch_local_ranks', fake_launch)
     monkeypatch.delenv('WORLD_SIZE', raising=False)
-    names = [f'/data/mic_{i:03d}.mrc' for i in range(37)]
+    names = [f'/data/mic_{i:03d}.mrc' for i in range(35)] + ['-odd name.mrc', '@at.mrc']
     monkeypatch.setattr(sys, 'stdin', io.StringIO('\n'.join(names) + '\n\n'))
-    assert tmain.main(['extract', '-m', 'resnet8_u32', '-r', '8', '--gpus', '4']) == 0
+    argv = ['extract', '-m', 'resnet8_u32', '-r', '8', '--gpus', '4']
+    assert tmain.main(argv) == 0
     assert seen['n'] == 4 and seen['names'] == names
-    import os
-    assert not os.path.exists([a for a in seen['cmd'] if a.startswith('@')][0][1:])      # the list file is removed afterwards
-    # a rank parses the same command line: the @file expands to the positional paths
-    from topaz_amd.commands import extract as cext
-    import argparse
-    p = argparse.ArgumentParser(fromfile_prefix_chars='@')
-    cext.add_arguments(p)
+    assert seen['cmd'][-len(argv):] == argv                   # nothing appended to the ranks' command line
+    assert not os.path.exists(seen['list'])                   # the list file is removed afterwards
+    # a rank (no paths on its command line) takes the list from that file, names untouched
+    from topaz_amd import extract as ext
     lf = os.path.join(os.path.dirname(__file__), '_tmp_list.txt')
     open(lf, 'w').write('\n'.join(names) + '\n')
+    monkeypatch.setenv('TOPAZ_AMD_INPUT_LIST', lf)
+    got = {}
+
+    def fake_score(model, paths, **kw):
+        got['paths'] = list(paths)
+        raise KeyboardInterrupt                               # (stop before any GPU work)
+
+    monkeypatch.setattr(ext, 'score_images', fake_score)
+    monkeypatch.setattr(ext.parallel, 'init_from_env', lambda *a, **k: (0, 0, 1), raising=False)
     try:
-        a = p.parse_args(['-m', 'resnet8_u32', '-r', '8', '--gpus', '4', '@' + lf])
+        ext.extract_particles([], 'resnet8_u32', 0, 1, -6.0, 8, 0, None, 5, 100, 5, -1, 0, False, None, False, '', 'coord', 1.0, 1.0)
+    except KeyboardInterrupt:
+        pass
     finally:
         os.unlink(lf)
-    assert a.paths == names
+    assert got.get('paths') == names
 
 
 def _sum_worker(rank, world, port, q):
@@ -251,8 +262,27 @@ def test_rank_cpu_sets_follow_the_gpu_numa_nodes(tmp_path):
     # numa_node -1 (single-socket hosts report it): fallback as well
     (root / 'class' / 'drm' / 'card1' / 'device' / 'numa_node').write_text('-1\n')
     assert cpu_sets_for_ranks(2, sysfs=str(root), allowed=range(4)) == [[0, 1], [2, 3]]
-    # a launched rank runs with the affinity the launcher announced to it
-    code = ('import os, sys\n'
+    # under a *_VISIBLE_DEVICES subset HIP device r is not DRM card r: no guessing from the card order (the rank resolves its
+    # own GPU through HIP's PCI address instead: explicit `nodes`)
+    (root / 'class' / 'drm' / 'card1' / 'device' / 'numa_node').write_text('0\n')
+    monkey_env = dict(os.environ)
+    try:
+        os.environ['ROCR_VISIBLE_DEVICES'] = '2,3'
+        assert cpu_sets_for_ranks(2, sysfs=str(root), allowed=range(32)) == [list(range(16)), list(range(16, 32))]
+        assert cpu_sets_for_ranks(2, sysfs=str(root), allowed=range(32), nodes=[1, 1]) == [
+            [8, 9, 10, 11, 12, 13, 14, 15], [24, 25, 26, 27, 28, 29, 30, 31]]
+    finally:
+        os.environ.clear()
+        os.environ.update(monkey_env)
+    # a launched rank pins ITSELF (every thread it already has) to the CPUs the launcher announced to it
+    code = ('import os, sys, threading, time\n'
+            f'sys.path.insert(0, {ROOT!r})\n'
+            'stop = threading.Event()\n'
+            'th = threading.Thread(target=stop.wait, daemon=True); th.start()\n'
+            'from topaz_amd.parallel import pin_this_rank\n'
             'want = sorted(int(c) for c in os.environ["TOPAZ_AMD_RANK_CPUS"].split(","))\n'
-            'sys.exit(0 if sorted(os.sched_getaffinity(0)) == want else 7)\n')
+            'got = pin_this_rank(int(os.environ["LOCAL_RANK"]), int(os.environ["LOCAL_WORLD_SIZE"]))\n'
+            'ok = sorted(got or []) == want and all(sorted(os.sched_getaffinity(int(t))) == want for t in os.listdir("/proc/self/task"))\n'
+            'stop.set()\n'
+            'sys.exit(0 if ok and len(os.listdir("/proc/self/task")) >= 1 else 7)\n')
     assert launch_local_ranks(2, [sys.executable, '-c', code]) == 0

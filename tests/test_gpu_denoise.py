@@ -279,3 +279,79 @@ def test_tomogram_tiles_sharded_like_ranks_would(gpu_ctx):
     assert np.abs(whole.cpu().numpy() - z['p32_16']).max() <= ATOL
     with pytest.raises(Exception, match='cannot be sharded'):
         dm.denoise_3d(tomo, -1, 0, shard=0, n_shards=2)
+
+
+@pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'ragged', 'unet3d'])
+def test_batched_patches_are_bit_identical(gpu_ctx, case):
+    """the same layer of up to 8 patches / tiles in ONE launch (conv_split_multi_kernel, runtime.hip rec_flush) against one
+    patch at a time: identical bits -- patches of different sizes (corner / edge / interior), patch counts that do not fill
+    the last batch, batch sizes 2, 3 and 8, windows on; the 3-D tiles through the plane-stacked modes"""
+    from topaz_amd.denoise import Denoise, Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    if case == 'unet3d':
+        z = load_golden('denoise3d_unet3d_nf8')
+        d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+        tomo = torch.from_numpy(z['tomo']).cuda()
+        run = lambda: d.model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()
+    else:
+        if case == 'bench_net':
+            d = Denoise(DenoiseNet('unet', oden.synthetic_unet_sd(11, nf=48, base_width=11, top_width=5)))
+            shape, patch, pad = (1500, 1330), 400, 300
+        elif case == 'pretrained':
+            d = Denoise('unet-v0.2.1')
+            shape, patch, pad = (1111, 1201), 256, 280
+        elif case == 'small':
+            d = Denoise('unet-small')
+            shape, patch, pad = (700, 900), 200, 120
+        elif case == 'fcnn':
+            d = Denoise('fcnn')
+            shape, patch, pad = (500, 640), 128, 64
+        else:
+            d = Denoise('unet-v0.2.1')
+            shape, patch, pad = (333, 1001), 97, 51
+        x = (np.random.RandomState(78).randn(*shape) * 3 + 1).astype(np.float32)
+        run = lambda: d.denoise(x, patch, pad)
+    try:
+        gpu_ctx.set_batch(0)
+        n0 = gpu_ctx.launches()
+        one = run()
+        n_one = gpu_ctx.launches() - n0
+        outs = {}
+        for b in (2, 3, 8):
+            gpu_ctx.set_batch(b)
+            n0 = gpu_ctx.launches()
+            outs[b] = run()
+            if b == 8:
+                n_batched = gpu_ctx.launches() - n0
+    finally:
+        gpu_ctx.set_batch(8)
+    assert np.isfinite(one).all()
+    for b, y in outs.items():
+        assert np.array_equal(one, y), (case, b)
+    print(f'{case}: {n_one} launches one patch at a time, {n_batched} batched by 8')
+    assert n_batched < n_one
+
+
+def test_fcnn_runs_wholly_on_the_2xf16_path(gpu_ctx):
+    """the pretrained fully convolutional denoiser (DenoiseNet2(64, width 11), denoising/models.py:52-66,597-598): 11x11 stem
+    and last conv as column kernels, the 11x11 64->64 body on its own 2xf16 tile -- no layer left on an fp32 kernel; output
+    within 1e-4 of the reference's golden and of the exact-fp32 kernels"""
+    import warnings
+    from topaz_amd.denoise import Denoise
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                    # (the mixed-program warning must not fire)
+        d = Denoise('fcnn')
+    n_conv, n_split, off = d.model.device_model.split_layers()
+    assert n_conv == 3 and n_split == 3, off
+    z = load_golden('denoise2d_pretrained')
+    y = d.denoise(z['x'], 64, 24)
+    assert _err(y, z['fcnn:p64_24']) <= ATOL
+    x = (np.random.RandomState(3).randn(700, 810) * 2 + 0.5).astype(np.float32)
+    a = d.denoise(x, 256, 100)
+    before = d.model.device_model.split_stats()
+    gpu_ctx.set_exact(True)
+    try:
+        b = d.denoise(x, 256, 100)
+    finally:
+        gpu_ctx.set_exact(False)
+    assert _err(a, b) <= ATOL and before[2] == 0

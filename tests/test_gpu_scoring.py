@@ -352,3 +352,51 @@ def test_pooled_resnet_user_pickle_and_larger_image(gpu_ctx):
     x = np.random.RandomState(77).randn(333, 290).astype(np.float32)
     sd = {k: v.numpy() for k, v in m.state_dict().items()}
     assert np.abs(_score(m, x) - oscoring.score('resnet8', sd, x, pooling=True)).max() <= ATOL
+
+
+@pytest.mark.parametrize('exact', [False, True], ids=['2xf16', 'exact_fp32'])
+def test_internal_tiling_is_bit_identical(gpu_ctx, exact):
+    """`topaz extract` scores any image that fits memory (extract.py:247-249); above the tiling limit tpz_model_forward scores a
+    2-D image tile by tile (each tile grown by the network's receptive halo) instead of refusing it for its 32-bit cell
+    offsets.  Forced here on images that also fit whole: identical bits -- the pretrained ResNet8 and a 64-unit one, tiles that
+    do not divide the image, a raw-count image (one range exponent for the whole image), both arithmetic paths."""
+    from topaz_amd.model.classifier import LinearClassifier
+    from topaz_amd.model.factory import load_model
+    nets = [load_model('resnet8_u32'), LinearClassifier('resnet8', oscoring.synthetic_resnet_sd('resnet8', 64, 7))]
+    rs = np.random.RandomState(5)
+    try:
+        gpu_ctx.set_exact(exact)
+        for m in nets:
+            for shape, tile, raw in (((300, 420), 96, False), ((257, 199), 128, True)):
+                x = rs.randn(*shape).astype(np.float32)
+                if raw:
+                    x = np.round(x * 300 + 2500).astype(np.float32)
+                gpu_ctx.set_tiling(40 << 20, 4096)
+                whole = _score(m, x)
+                gpu_ctx.set_tiling(1, tile)
+                tiled = _score(m, x)
+                assert whole.shape == x.shape and np.isfinite(whole).all()
+                assert np.array_equal(whole, tiled), (shape, tile, raw)
+    finally:
+        gpu_ctx.set_tiling(40 << 20, 4096)
+        gpu_ctx.set_exact(False)
+
+
+def test_large_frame_is_scored_in_tiles(gpu_ctx):
+    """a frame above the default tiling limit (here 7000 x 6200 = 43.4 Mpx through the pretrained ResNet8): sampled windows
+    agree with the oracle run on the window's own crop (translation equivariance away from the borders)"""
+    from topaz_amd.model.factory import load_model
+    m = load_model('resnet8_u32')
+    H, W = 7000, 6200
+    x = np.random.RandomState(9).randn(H, W).astype(np.float32)
+    y = _score(m, x)
+    assert y.shape == (H, W)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    R = 71                                                   # (width of the filled ResNet8: the oracle crop's own halo)
+    for (cy, cx) in ((4096, 4096), (100, 6100), (6900, 3000)):
+        y0, x0 = max(0, cy - 64 - R), max(0, cx - 64 - R)
+        y1, x1 = min(H, cy + 64 + R), min(W, cx + 64 + R)
+        ref = oscoring.score('resnet8', sd, x[y0:y1, x0:x1].copy())
+        a, b = (R if y0 > 0 else 0), (R if x0 > 0 else 0)
+        c, d = (ref.shape[0] - R if y1 < H else ref.shape[0]), (ref.shape[1] - R if x1 < W else ref.shape[1])
+        assert np.abs(y[y0 + a:y0 + c, x0 + b:x0 + d] - ref[a:c, b:d]).max() <= 1e-4

@@ -145,15 +145,20 @@ def test_resnet_u64_runs_split_and_matches_oracle(gpu_ctx, arch, bn):
 
 
 def test_out_of_range_activations_rerun_in_fp32(gpu_ctx):
-    """Input scaled so that feature maps exceed 65504: the device flag trips and the image is re-run on the
-    fp32 kernels -- the scores still match the oracle."""
+    """Range scaling off, input scaled so that feature maps exceed 65504: the device flag trips and the image is re-run on
+    the fp32 kernels -- the scores still match the oracle.  (With range scaling on -- the default -- the same image stays on
+    the 2xf16 path: next test.)"""
     from oracle import scoring as oscoring
     m, sd = _resnet('resnet8', 64, False)
     x = (np.random.RandomState(4).randn(140, 150) * 3e4).astype(np.float32)
     ref = oscoring.score('resnet8', sd, x)
     dm = m.device_model
     before = dm.split_stats()
-    y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    gpu_ctx.set_range(False)
+    try:
+        y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    finally:
+        gpu_ctx.set_range(True)
     after = dm.split_stats()
     assert after[2] == before[2] + 1, 'expected the fp32 re-run'
     assert np.isfinite(y).all()
@@ -165,6 +170,60 @@ def test_out_of_range_activations_rerun_in_fp32(gpu_ctx):
     finally:
         gpu_ctx.set_exact(False)
     assert np.array_equal(y, y32), 'the re-run must be the fp32 path itself'
+
+
+@pytest.mark.parametrize('net', ['resnet8_u64', 'resnet8_u64_bn', 'resnet16_u64', 'resnet8_u32_pretrained', 'conv63_u32_bn'])
+def test_raw_count_micrograph_stays_on_the_2xf16_path(gpu_ctx, net):
+    """`topaz extract` does not normalise what it scores (extract.py:234-249): an un-normalised, detector-count micrograph
+    (uint16 range, mean 3000) would overflow f16 in the stem.  The pass runs on x * 2^-s with every bias scaled by 2^-s and
+    multiplies the logits back (the network is homogeneous in (input, biases); powers of two are exact): NO fp32 re-run, logits
+    as close to a float64 evaluation as torch's own fp32 evaluation is (<= 2x its error), and equal to the exact-fp32 kernels'
+    within the same bound."""
+    from oracle import scoring as oscoring
+    if net == 'resnet8_u32_pretrained':
+        from topaz_amd.model.factory import load_model
+        m = load_model('resnet8_u32')
+        m.eval(); m.fill(); m.cuda()
+        arch, sd = 'resnet8', {k: v.numpy() for k, v in m.state_dict().items()}
+    elif net == 'conv63_u32_bn':
+        from topaz_amd.model.classifier import LinearClassifier
+        arch, sd = 'conv63', oscoring.synthetic_basic_sd((7, 5, 5, 5), 32, 5, bn=True)
+        m = LinearClassifier(arch, sd)
+        m.eval(); m.fill(); m.cuda()
+    else:
+        arch = net.split('_')[0]
+        m, sd = _resnet(arch, 64, net.endswith('_bn'))
+    rs = np.random.RandomState(21)
+    x = np.clip(np.round(rs.randn(200, 232) * 400 + 3000), 0, 65535).astype(np.float32)
+    x[17, 40] = 65535.0                                   # a hot pixel
+    ref64 = oscoring.score(arch, sd, x, dtype=torch.float64)
+    ref32 = oscoring.score(arch, sd, x)
+    dm = m.device_model
+    before = dm.split_stats()
+    y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    after = dm.split_stats()
+    assert after[1] == before[1] + 1 and after[2] == before[2], f'fp32 re-runs: {after[2] - before[2]}'
+    e_ours = float(np.abs(y - ref64).max())
+    e_torch = float(np.abs(ref32.astype(np.float64) - ref64).max())
+    scale = float(np.abs(ref64).max())
+    print(f'{net}: |logit| up to {scale:.3g}; error vs float64: 2xf16 + range scaling {e_ours:.3g}, torch fp32 {e_torch:.3g}')
+    assert e_ours <= max(2.0 * e_torch, 2e-6 * scale)
+    gpu_ctx.set_exact(True)
+    try:
+        y32 = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    finally:
+        gpu_ctx.set_exact(False)
+    assert float(np.abs(y - y32).max()) <= max(3.0 * e_torch, 3e-6 * scale)
+    # an image inside +-32 is not touched: identical bits with the switch off
+    xn = ((x - 3000) / 400).astype(np.float32)
+    xn[17, 40] = 31.0
+    a = m(torch.from_numpy(xn).cuda()[None, None])[0, 0].cpu().numpy()
+    gpu_ctx.set_range(False)
+    try:
+        b = m(torch.from_numpy(xn).cuda()[None, None])[0, 0].cpu().numpy()
+    finally:
+        gpu_ctx.set_range(True)
+    assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('shape', [(256, 320), (253, 190), (150, 140)])

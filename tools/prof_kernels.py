@@ -23,6 +23,21 @@ def main(what, exact=False):
         x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
         dn = Denoise(DenoiseNet('unet', sw.unet_sd(11, nf=48, base_width=11, top_width=5)))
         fn = lambda: dn.denoise_device(x, 1024, 500)
+    elif what in ('fcnn', 'unet-small', 'unet-v0.2.1'):
+        x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
+        dn = Denoise(what)
+        fn = lambda: dn.denoise_device(x, 1024, 500)
+    elif what in ('resnet8_u32', 'resnet16_u32'):
+        from topaz_amd.model.factory import load_model
+        x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
+        m = load_model(what)
+        m.eval(); m.fill(); m.cuda()
+        fn = lambda: rt.nms(m(x[None, None])[0, 0], 14, -6.0)
+    elif what == 'conv127':
+        x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
+        m = LinearClassifier('conv127', sw.basic_sd((7, 5, 5, 5, 5), 32, 7))
+        m.eval(); m.fill(); m.cuda()
+        fn = lambda: rt.nms(m(x[None, None])[0, 0], 14, -6.0)
     elif what == 'extract':
         x = torch.from_numpy(np.random.RandomState(1000).randn(4096, 4096).astype(np.float32)).cuda()
         m = sw.hip_resnet('resnet8', 64, 7)[0]

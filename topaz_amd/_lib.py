@@ -76,9 +76,15 @@ _SIGNATURES = {
     'tpz_transpose_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     'tpz_ctx_set_exact': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_lanes': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_batch': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_range': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_raster': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_tiling': (C.c_int, [_P, C.c_longlong, C.c_int]),
+    'tpz_prof_launches': (C.c_longlong, [_P]),
     'tpz_ctx_set_roi': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_persist': (C.c_int, [_P, C.c_int, C.c_int]),
     'tpz_model_split_stats': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    'tpz_model_split_layers': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     'tpz_conv_split_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, _P, C.c_int, _P, _P, _P, C.c_float, _P, C.POINTER(C.c_int)]),
     'tpz_prof_enable': (C.c_int, [_P, C.c_int]),

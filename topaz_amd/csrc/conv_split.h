@@ -380,8 +380,11 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 // concat, space-to-depth skip cell, folded projection), bit 1: plane-stacked 3-D.  The library launches MODE 0 whenever a layer
 // needs neither (every layer of the scoring networks but the folded ones, most of the U-Nets'): its per-step scalar code then
 // carries none of the other modes' selects and branches.
-template <class C, int EPI, int ABL = 0, int MODE = 3>
-__global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
+// (the body of the kernels below: `a` = the launch's arguments, (bid_x, bid_y, bid_z) of a (grid_x, grid_y, .) grid = this
+// workgroup's place in it -- blockIdx / gridDim for a launch of its own, the entry's share of a batched launch otherwise)
+template <class C, int EPI, int ABL, int MODE>
+__device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z,
+                                                const unsigned grid_x, const unsigned grid_y) {
     constexpr int D = C::D, MW = C::MW, NW = C::NW, NFC = C::NFC;
     constexpr bool HAS2 = (MODE & 1) != 0, VOLM = (MODE & 2) != 0;
     // MODE bit 3 (with bits 0 and 1): every chunk of a plane-stacked two-source launch comes from ONE tensor (SplitArgs::
@@ -449,23 +452,37 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     unsigned tile_L = 0, tile_end = 0, tile_stride = 1;       // PERSIST: this workgroup's tiles L, L + stride, ... < end
     if constexpr (PERSIST) {
         const unsigned nt = (unsigned)a.n_tiles;
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, q = nt / 8, r = nt % 8;
+        const unsigned xcd = bid_x & 7u, j = bid_x >> 3, q = nt / 8, r = nt % 8;
         const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         tile_end = start + q + (xcd < r ? 1u : 0u);
-        tile_stride = gridDim.x >> 3;
+        tile_stride = grid_x >> 3;
         tile_L = start + j;
         if (tile_L >= tile_end) return;                       // (more workgroups than tiles in this XCD's run)
         set_tile_linear(tile_L);
     } else {
-        int bx = blockIdx.x, by = blockIdx.y;
+        int bx = (int)bid_x, by = (int)bid_y;
         if (a.xcd_swizzle) {
-            const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned nwg = grid_x * grid_y, orig = bid_x + grid_x * bid_y;
             const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
             const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-            bx = (int)(wgid % gridDim.x);
-            by = (int)(wgid / gridDim.x);
+            if (a.xcd_swizzle == 2) {
+                // PATCH raster: the grid is padded to whole 8 x 4 blocks of tiles and an XCD's run of workgroup ids walks them
+                // block by block, so the 32 tiles its CUs hold at a time form a compact patch whose halos overlap in that
+                // XCD's L2 (a row-major run shares columns only: 25 GB fetched for 8.7 GB of tensors on the 5x5 d4 layer).
+                // Rows are taken phase-major -- r = phase * bands + band -- because the D row phases of a dilated layer share
+                // nothing, while neighbouring bands of one phase share K - 1 rows.
+                const unsigned blk = wgid >> 5, in = wgid & 31u, nbx = grid_x >> 3;
+                const unsigned byb = blk / nbx, tr = byb * 4 + (in >> 3), bands = (unsigned)a.tiles_y / (unsigned)D;
+                bx = (int)((blk - byb * nbx) * 8 + (in & 7u));
+                if (bx >= a.tiles_x || tr >= (unsigned)a.tiles_y) return;       // (padding of the last blocks)
+                const unsigned ph = tr / bands;
+                by = (int)((tr - ph * bands) * (unsigned)D + ph);
+            } else {
+                bx = (int)(wgid % grid_x);
+                by = (int)(wgid / grid_x);
+            }
         }
-        set_tile(bx, by, (int)blockIdx.z);
+        set_tile(bx, by, (int)bid_z);
     }
     const bool vol = VOLM && (a.KZ > 1 || a.Din > 1);        // plane-stacked 3-D addressing
 
@@ -1137,6 +1154,43 @@ __global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(c
     } else if constexpr (EPI != EPI_PLAIN_F32) {
         if (__any(big) && lane == 0) atomicOr(a.flag, 1u);
     }
+}
+
+template <class C, int EPI, int ABL = 0, int MODE = 3>
+__global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_kernel(const SplitArgs a) {
+    conv_split_body<C, EPI, ABL, MODE>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// BATCHED launch: the same layer of up to SPLIT_MULTI_MAX independent images (the patches of a patched denoise, the tiles of a
+// tomogram: denoise.py:299-323, 340-377) in ONE grid.  The deep levels of a U-Net are 16-tile launches on a 256-CU chip (20 - 60
+// us each whatever they compute, ~400 of them per micrograph); entry j's workgroups are the linear ids [first[j], first[j+1])
+// (first[] rounded to multiples of 8: the XCD of a workgroup stays its tile index mod 8; the gap workgroups exit), laid out
+// x-fastest over its own (tiles_x, tiles_y, z) grid.  The whole table travels in the kernel-argument segment and is read
+// through the scalar cache like the arguments of a single launch: the entry index is wave-uniform.
+enum { SPLIT_MULTI_MAX = 8 };
+struct SplitMulti {
+    unsigned n, first[SPLIT_MULTI_MAX + 1];
+    unsigned pad_[6];                            // (the entries start 64-byte aligned)
+    SplitArgs a[SPLIT_MULTI_MAX];
+};
+static_assert(sizeof(SplitMulti) <= 4096, "kernel-argument segment");
+
+template <class C, int EPI, int MODE>
+__global__ __launch_bounds__(C::THREADS, C::WGS_PER_CU) void conv_split_multi_kernel(const SplitMulti) {
+    // (addressed through the segment pointer, not through the parameter: indexing a by-value aggregate with a run-time index
+    // makes the compiler copy it to scratch)
+    typedef const __attribute__((address_space(4))) SplitMulti* multi_ptr_t;
+    const multi_ptr_t m = (multi_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned b = blockIdx.x;
+    unsigned j = 0;                              // (first[] is monotone and first[i >= n] = the grid size: no bound check)
+#pragma unroll
+    for (unsigned i = 1; i < SPLIT_MULTI_MAX; ++i) j += b >= m->first[i] ? 1u : 0u;
+    const unsigned l = b - m->first[j];
+    const SplitArgs& a = *(const SplitArgs*)&m->a[j];
+    const unsigned gx = (unsigned)a.tiles_x, gy = (unsigned)a.tiles_y, gxy = gx * gy;
+    const unsigned bz = l / gxy, rem = l - bz * gxy, by = rem / gx;
+    if (l >= (unsigned)a.n_tiles) return;        // (padding workgroups between two entries)
+    conv_split_body<C, EPI, 0, MODE>(a, rem - by * gx, by, bz, gx, gy);
 }
 
 }  // namespace tpz

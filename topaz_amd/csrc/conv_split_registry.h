@@ -15,6 +15,9 @@ struct SplitKernelInfo {
     // steps of one tile's K loop over `cells` (virtual) cells
     int stages(int cells) const { return cont ? ((Q / CC) * cells + 3) / 4 : (cells + CC - 1) / CC * NSTEP; }
     hipError_t (*launch)(const SplitArgs&, dim3 grid, hipStream_t);
+    // the same layer of n <= SPLIT_MULTI_MAX independent images in one grid (conv_split_multi_kernel); list[i].n_tiles = the
+    // workgroups of entry i's own grid.  nullptr: this configuration launches one image at a time
+    hipError_t (*launch_multi)(const SplitArgs* const* list, int n, hipStream_t);
     void (*make_plan)(const SplitPlanKey&, std::vector<SplitStep>&);     // the K-loop schedule the kernel reads (SplitArgs::plan)
     char name[160];
 };
@@ -78,6 +81,55 @@ hipError_t launch_split_cfg(const SplitArgs& a, dim3 grid, hipStream_t s) {
     return hipGetLastError();
 }
 
+// which instantiation (MODE) a launch takes: 0 plain 2-D, 1 2-D with a second source, 2 / 11 / 3 plane-stacked 3-D with one
+// source / two sources chunk-uniform / two sources in general
+inline int split_mode_of(const SplitArgs& a) {
+    if (!a.in2 && a.KZ <= 1 && a.Din <= 1) return 0;
+    if (a.KZ <= 1 && a.Din <= 1) return 1;
+    if (!a.in2) return 2;
+    return a.vol_srcmajor ? 11 : 3;
+}
+
+// batched launches exist for the 4-wave tiles (every layer of the U-Nets), modes 0 / 1 / 2 / 11
+template <class C, int EPI>
+hipError_t launch_split_multi_cfg(const SplitArgs* const* list, int n, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_multi_kernel<C, EPI, 0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_multi_kernel<C, EPI, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_multi_kernel<C, EPI, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_multi_kernel<C, EPI, 11>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (n < 1 || n > SPLIT_MULTI_MAX) return hipErrorInvalidValue;
+    SplitMulti m;
+    m.n = (unsigned)n;
+    unsigned total = 0;
+    const int mode = split_mode_of(*list[0]);
+    for (int i = 0; i < n; ++i) {
+        if (split_mode_of(*list[i]) != mode || list[i]->n_tiles < 1) return hipErrorInvalidValue;
+        m.first[i] = total;
+        m.a[i] = *list[i];
+        total = (total + (unsigned)list[i]->n_tiles + 7u) & ~7u;
+    }
+    for (int i = n; i <= SPLIT_MULTI_MAX; ++i) m.first[i] = total;
+    const dim3 grid(total, 1, 1);
+    if (mode == 0) hipLaunchKernelGGL((conv_split_multi_kernel<C, EPI, 0>), grid, dim3(C::THREADS), C::LDS_BYTES, s, m);
+    else if (mode == 1) hipLaunchKernelGGL((conv_split_multi_kernel<C, EPI, 1>), grid, dim3(C::THREADS), C::LDS_BYTES, s, m);
+    else if (mode == 2) hipLaunchKernelGGL((conv_split_multi_kernel<C, EPI, 2>), grid, dim3(C::THREADS), C::LDS_BYTES, s, m);
+    else if (mode == 11) hipLaunchKernelGGL((conv_split_multi_kernel<C, EPI, 11>), grid, dim3(C::THREADS), C::LDS_BYTES, s, m);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <class C>
 SplitSlot split_slot_of(int step, int kb) { return C::slot(step, kb); }
 template <class C>
@@ -95,6 +147,8 @@ struct SplitRegistrar {
         i.cont = C::CONT ? 1 : 0; i.Q = C::Q;
         i.cont_slot = &split_cont_slot_of<C>;
         i.launch = &launch_split_cfg<C, EPI>;
+        i.launch_multi = nullptr;
+        if constexpr (C::WAVES == 4 && EPI != EPI_HEAD) i.launch_multi = &launch_split_multi_cfg<C, EPI>;
         i.make_plan = &split_make_plan<C>;
         if (C::SPS == 1)
             snprintf(i.name, sizeof i.name, "conv_split_kernel<K=%dx%d,D=%d,MT=%d,TH=%d,TW=%d,CC=%d,W=%d,EPI=%d>", i.K, i.KX,

@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the hot path: direct convolution for 1-output-channel layers
 // and 1->1 filters, 2x max-pool, mean/std reductions, affine maps, crop/paste and 3-D tiling.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "split_fmt.h"
@@ -442,6 +443,70 @@ hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, 
     if (n == 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(affine_dev_kernel, dim3(blocks), dim3(256), 0, s, x, D, H, W, ps, pitch, d_p, y);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Range scaling of a scoring pass.  `topaz extract` scores micrographs as they come (extract.py:234-249: no normalisation), and a
+// raw-count image (mean 10^3 .. 10^4) drives the activations of the 2xf16 path past the f16 range.  A scoring network is
+// positively homogeneous in (input, biases) jointly -- convolutions, PReLU / ReLU, max-pools, residual adds, eval-BN affines and
+// the linear head are -- so f(2^-s x; 2^-s b) = 2^-s f(x; b), exactly (powers of two): the pass runs on x * 2^-s with every
+// bias-like vector scaled alike and multiplies its result by 2^s.  s is chosen per image on the device (no host round trip).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;              // |x| as bits: monotone for non-negative floats; NaN patterns sort above infinity
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    __shared__ unsigned sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = sm[w] > m ? sm[w] : m;
+        if (m) atomicMax(out, m);
+    }
+}
+
+__global__ __launch_bounds__(256) void range_finish_kernel(unsigned* __restrict__ scratch, float target, float* __restrict__ rng,
+                                                           const float* __restrict__ src, float* __restrict__ dst, size_t n_vec) {
+    const unsigned bits = *scratch;
+    int s = 0;
+    if (bits < 0x7f800000u) {                       // finite (an image with inf / NaN is left alone: the overflow flag decides)
+        const float mx = __uint_as_float(bits);
+        while (s < 96 && ldexpf(mx, -s) > target) ++s;
+    }
+    const float down = ldexpf(1.f, -s), up = ldexpf(1.f, s);
+    for (size_t i = threadIdx.x; i < n_vec; i += 256) dst[i] = src[i] * down;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rng[0] = down; rng[1] = 0.f; rng[2] = up; rng[3] = (float)s;
+        *scratch = 0;                               // ready for the next image on this stream
+    }
+}
+
+hipError_t launch_range_fit(const float* x, size_t n, float target, unsigned* scratch, float* rng, const float* src, float* dst,
+                            size_t n_vec, hipStream_t s) {
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    if (n) hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, scratch);
+    hipLaunchKernelGGL(range_finish_kernel, dim3(1), dim3(256), 0, s, scratch, target, rng, src, dst, n_vec);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void unscale_kernel(float* __restrict__ y, size_t n, const float* __restrict__ rng, float add) {
+    const float up = rng[2];
+    if (up == 1.f && add == 0.f) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = y[i] * up + add;
+}
+
+hipError_t launch_unscale(float* y, size_t n, const float* rng, float add, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(unscale_kernel, dim3(blocks), dim3(256), 0, s, y, n, rng, add);
     return hipGetLastError();
 }
 

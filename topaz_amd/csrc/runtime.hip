@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <string>
@@ -62,6 +63,18 @@ static const bool g_no_lanes = getenv("TPZ_NO_LANES") != nullptr;      // patche
 // TPZ_NO_ROI=1: every layer of a patch computes its whole tensor (A/B switch; see need_regions)
 static const bool g_no_roi = getenv("TPZ_NO_ROI") != nullptr;
 static const bool g_persist = getenv("TPZ_NO_PERSIST") == nullptr;      // persistent workgroups for the large plain conv_split launches
+// TPZ_BATCH=n: the same layer of n patches / tiles of an image in one launch (0 / TPZ_NO_BATCH=1: patch lanes instead)
+// TPZ_TRACE_HOST=1: host time of the recording and issuing phases of a batched pass, on stderr
+static const bool g_trace_host = getenv("TPZ_TRACE_HOST") != nullptr;
+static double host_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static int env_batch() {
+    if (getenv("TPZ_NO_BATCH")) return 0;
+    const char* e = getenv("TPZ_BATCH");
+    const int n = e ? atoi(e) : (int)tpz::SPLIT_MULTI_MAX;
+    return n < 0 ? 0 : n > (int)tpz::SPLIT_MULTI_MAX ? (int)tpz::SPLIT_MULTI_MAX : n;
+}
 
 #ifndef TPZ_N_LANES
 #define TPZ_N_LANES 4
@@ -78,6 +91,19 @@ struct ProfRec {
 struct ProfAcc {
     double ms = 0, flops = 0, bytes = 0;
     long long n = 0;
+};
+
+// One deferred launch of a batched pass (tpz_ctx::rec): a conv_split launch (ks != nullptr: `a` complete but for the stream,
+// a.n_tiles = the workgroups of `grid`) that rec_flush may merge with the same layer's launch of other images, or any other
+// launch as a closure over its arguments.
+struct RecOp {
+    const SplitKernelInfo* ks = nullptr;
+    SplitArgs a;
+    dim3 grid;
+    std::function<hipError_t(hipStream_t)> fn;
+    int cls = 2;
+    double flops = 0, bytes = 0;
+    const void* key = nullptr;
 };
 
 struct tpz_ctx {
@@ -115,11 +141,32 @@ struct tpz_ctx {
     bool roi_enabled = !g_no_roi;             // tpz_ctx_set_roi: patches compute only what their kept centre depends on
     int persist_mode = g_persist ? 1 : 0;     // tpz_ctx_set_persist: 0 never, 1 large launches (default), 2 every eligible launch
     int persist_wgs = 0;                      // ... workgroups of a persistent grid (0: CUs x workgroups per CU)
+    // Batched passes (rec_begin / rec_select / rec_flush): the launches of up to SPLIT_MULTI_MAX independent images (patches of
+    // a micrograph, tiles of a tomogram) are RECORDED, image by image, each image on a workspace pool of its own, and then
+    // issued layer by layer -- the conv_split launches of the same layer as ONE grid (conv_split_multi_kernel).  The deep
+    // levels of a U-Net are 16-tile launches on a 256-CU chip; batched they are 8 x as large and 8 x fewer.
+    int batch = env_batch();                  // images per batch (tpz_ctx_set_batch); 0: off (patch lanes)
+    bool rec_on = false;
+    double rec_t0 = 0;                        // (TPZ_TRACE_HOST)
+    int rec_cur = 0;
+    std::vector<RecOp> rec[tpz::SPLIT_MULTI_MAX];
+    std::vector<Buf> rec_pools[tpz::SPLIT_MULTI_MAX];
+    long long n_launches = 0;                 // kernel launches issued (tpz_prof_launches)
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
     int nrm_next = 0;
     unsigned int* d_counters = nullptr;     // NMS_COUNTERS entries (nms_common)
     float* d_zeros = nullptr;     // 256 B of zeros: DMA source of padded / out-of-image elements
+    // range-scaled scoring pass (tpz_model_forward): every bias-like vector is read `bias_shift` floats further on (the model's
+    // scaled copy of its bias arena), the fused head adds no bias (the un-scaling pass does)
+    ptrdiff_t bias_shift = 0;
+    bool scaled_pass = false;
+    unsigned* d_absmax = nullptr; // scratch word of launch_range_fit
+    bool range_scaling = getenv("TPZ_NO_RANGE") == nullptr;       // tpz_ctx_set_range
+    bool raster = getenv("TPZ_NO_RASTER") == nullptr;             // tpz_ctx_set_raster: patch raster of the 8-wave tiles' grids
+    // internal tiling of tpz_model_forward (run_image): 2-D images above tile_limit_px pixels are scored in tile_size^2 tiles
+    long long tile_limit_px = 40LL << 20;
+    int tile_size = 4096;
     unsigned* d_flag = nullptr;   // f16-range overflow flag of the 2xf16 path
     unsigned* h_flag = nullptr;   // pinned copy
     bool exact = g_exact_fp32;    // fp32 kernels only
@@ -294,6 +341,115 @@ static void prof_flush(tpz_ctx* ctx) {
     ctx->recs.clear();
 }
 
+// ---- launches: issued at once on the ctx stream or, in a batched pass, recorded for rec_flush
+// fn(stream) launches the kernel(s); cls / flops / key / bytes label it for the profiler
+template <class F>
+static hipError_t enqueue(tpz_ctx* ctx, int cls, double flops, const void* key, double bytes, F&& fn) {
+    if (ctx->rec_on) {
+        RecOp op;
+        op.fn = std::forward<F>(fn);
+        op.cls = cls; op.flops = flops; op.key = key; op.bytes = bytes;
+        ctx->rec[ctx->rec_cur].push_back(std::move(op));
+        return hipSuccess;
+    }
+    prof_begin(ctx, cls, flops, key, bytes);
+    const hipError_t e = fn(ctx->stream);
+    prof_end(ctx);
+    ++ctx->n_launches;
+    return e;
+}
+template <class F>
+static hipError_t enqueue(tpz_ctx* ctx, F&& fn) { return enqueue(ctx, 2, 0.0, nullptr, 0.0, std::forward<F>(fn)); }
+
+static int rec_begin(tpz_ctx* ctx) {
+    if (g_trace_host) ctx->rec_t0 = host_now_ms();
+    for (auto& r : ctx->rec) r.clear();
+    ctx->rec_on = true;
+    ctx->rec_cur = 0;
+    ctx->pool_cur = &ctx->rec_pools[0];
+    return 0;
+}
+// image i of the batch: its launches are recorded in its own list, its tensors come from its own pool (the images of a batch
+// run interleaved: nothing of one may alias anything of another)
+static void rec_select(tpz_ctx* ctx, int i) {
+    ctx->rec_cur = i;
+    ctx->pool_cur = &ctx->rec_pools[i];
+}
+// leaves a batched pass: whatever is still recorded (an error on the way) is dropped
+static void rec_abort(tpz_ctx* ctx) {
+    ctx->rec_on = false;
+    ctx->pool_cur = &ctx->pool;
+    for (auto& r : ctx->rec) r.clear();
+}
+// Issue everything recorded.  Every list keeps its own order (the dependencies inside an image); across the lists the
+// launches are independent, so each round first replays the non-convolution launches at the head of every list and then takes
+// the conv_split launch at the head of the first unfinished list together with every other list's head that is the same
+// kernel in the same mode with the same K-loop plan: one grid.
+static int rec_flush(tpz_ctx* ctx) {
+    ctx->rec_on = false;
+    ctx->pool_cur = &ctx->pool;
+    const double t_flush0 = g_trace_host ? host_now_ms() : 0.0;
+    long long n_issued = 0;
+    const int n = (int)tpz::SPLIT_MULTI_MAX;
+    size_t cur[tpz::SPLIT_MULTI_MAX] = {};
+    int rc = 0;
+    for (;;) {
+        bool any = false;
+        for (int i = 0; i < n && !rc; ++i) {
+            auto& L = ctx->rec[i];
+            while (cur[i] < L.size() && !L[cur[i]].ks && !rc) {
+                RecOp& op = L[cur[i]++];
+                prof_begin(ctx, op.cls, op.flops, op.key, op.bytes);
+                const hipError_t e = op.fn(ctx->stream);
+                prof_end(ctx);
+                ++ctx->n_launches;
+                ++n_issued;
+                if (e != hipSuccess) rc = fail(ctx, "launch failed: %s", hipGetErrorString(e));
+            }
+            if (cur[i] < L.size()) any = true;
+        }
+        if (rc || !any) break;
+        int lead = -1;
+        for (int i = 0; i < n; ++i)
+            if (cur[i] < ctx->rec[i].size()) { lead = i; break; }
+        const RecOp& o0 = ctx->rec[lead][cur[lead]];
+        const SplitArgs* list[tpz::SPLIT_MULTI_MAX];
+        int who[tpz::SPLIT_MULTI_MAX], m = 0;
+        double flops = 0, bytes = 0;
+        for (int i = lead; i < n; ++i) {
+            if (cur[i] >= ctx->rec[i].size()) continue;
+            const RecOp& o = ctx->rec[i][cur[i]];
+            if (o.ks != o0.ks || o.a.plan != o0.a.plan || split_mode_of(o.a) != split_mode_of(o0.a)) continue;
+            if (i != lead && !o0.ks->launch_multi) continue;
+            list[m] = &o.a; who[m++] = i;
+            flops += o.flops; bytes += o.bytes;
+        }
+        prof_begin(ctx, 0, flops, o0.ks->name, bytes);
+        hipError_t e;
+        if (m == 1) {
+            SplitArgs a1 = o0.a;
+            a1.n_tiles = 0;                    // (a launch of its own: n_tiles > 0 would select the persistent kernel)
+            e = o0.ks->launch(a1, o0.grid, ctx->stream);
+        } else {
+            e = o0.ks->launch_multi(list, m, ctx->stream);
+        }
+        prof_end(ctx);
+        ++ctx->n_launches;
+        ++n_issued;
+        if (e != hipSuccess) rc = fail(ctx, "conv_split launch failed: %s", hipGetErrorString(e));
+        for (int k = 0; k < m; ++k) ++cur[who[k]];
+    }
+    if (g_trace_host) {
+        size_t n_ops = 0;
+        int n_img = 0;
+        for (auto& r : ctx->rec) { n_ops += r.size(); n_img += r.empty() ? 0 : 1; }
+        fprintf(stderr, "[tpz host] batch of %d images: %zu launches recorded in %.3f ms, issued as %lld in %.3f ms\n", n_img, n_ops,
+                t_flush0 - ctx->rec_t0, n_issued, host_now_ms() - t_flush0);
+    }
+    for (auto& r : ctx->rec) r.clear();
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
@@ -368,7 +524,14 @@ struct tpz_model {
     int n_slots = 0;
     std::vector<int> last_use;
     std::vector<void*> dev_allocs;
-    bool split_ok = false;                // every layer has a 2xf16 kernel (or is the stem feeding them)
+    // bias-like vectors (conv biases, folded biases, eval-BN shifts) of all layers in one arena + a scratch copy of the same
+    // size that a range-scaled pass fills with 2^-s times the originals (tpz_model_forward)
+    float* d_bias_arena = nullptr;
+    float* d_bias_scaled = nullptr;
+    size_t n_bias_arena = 0;
+    int n_conv = 0, n_conv_split = 0;     // convolution layers; those with a 2xf16 kernel (prepare_split)
+    std::string off_path;                 // ... the others, "#layer KxK dD cin->cout, ..."
+    bool split_ok = false;                // at least one layer has a 2xf16 kernel: the program runs in split mode
     long long n_split = 0, n_fallback = 0;
 };
 
@@ -402,6 +565,9 @@ static void set_dense(Slot& s, float* p, int C, int D, int H, int W) {
     s.pitch = W; s.ps = (long long)H * W; s.cs = s.ps * D;
     s.set = true;
 }
+
+// a bias-like vector as the current pass reads it (the scaled copy in a range-scaled pass)
+static inline const float* bias_view(const tpz_ctx* ctx, const float* p) { return p ? p + ctx->bias_shift : nullptr; }
 
 static int upload(tpz_ctx* ctx, tpz_model* m, const float* h, size_t n, float** out) {
     float* d = nullptr;
@@ -1047,6 +1213,22 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         m->last_use[P.src] = std::max(m->last_use[P.src], i);       // conv1 now reads the projection's input itself
     }
     m->split_ok = any_split;
+    // how much of the model the 2xf16 path covers (tpz_model_split_layers): a mixed program is correct -- the other layers run
+    // on their fp32 kernels with a format conversion either side -- but several times slower than it looks
+    m->n_conv = m->n_conv_split = 0;
+    m->off_path.clear();
+    for (int i = 0; i < nl; ++i) {
+        const LayerRT& rt = m->layers[i];
+        const tpz_layer& L = rt.L;
+        if (L.op != TPZ_OP_CONV) continue;
+        ++m->n_conv;
+        const bool on = rt.ks || rt.ks_stem || rt.ks_last || rt.sphase.valid || rt.ki_stem_split ||
+                        (rt.folded_into >= 0 && m->layers[rt.folded_into].ks_fold);
+        if (on) { ++m->n_conv_split; continue; }
+        char buf[96];
+        snprintf(buf, sizeof buf, "%s#%d %dx%d d%d %d->%d", m->off_path.empty() ? "" : ", ", i, L.k, L.k, L.dil, L.cin, L.cout);
+        if (m->off_path.size() < 400) m->off_path += buf;
+    }
     return 0;
 }
 
@@ -1073,9 +1255,9 @@ static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int 
     if ((size_t)ki.NCH * (size_t)std::max(a.cs1, a.cs2) * 4 >= ((size_t)1 << 32))
         return fail(ctx, "image too large for one launch: process it in patches");
     dim3 grid(a.tiles_x, a.tiles_y * a.tiles_z, n_cog / a.cog_inner);
-    prof_begin(ctx, 0, flops, ki.name);
-    hipError_t e = ki.launch(a, grid, ctx->stream);
-    prof_end(ctx);
+    const ConvKernelInfo* kip = &ki;
+    const ConvArgs ac = a;
+    hipError_t e = enqueue(ctx, 0, flops, ki.name, 0.0, [kip, ac, grid](hipStream_t st) { return kip->launch(ac, grid, st); });
     HIPCHK(ctx, e);
     return 0;
 }
@@ -1163,12 +1345,12 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
     a.in = reinterpret_cast<const uint4*>(s1.p);
     a.wpk = reinterpret_cast<const uint4*>(fold ? rt.d_wfold : rt.d_wsplit);
     a.wscale = fold ? rt.d_wscale_fold : rt.d_wscale;
-    a.bias = fold ? rt.d_bias_fold : rt.d_bias;
+    a.bias = bias_view(ctx, fold ? rt.d_bias_fold : rt.d_bias);
     a.res = sres ? reinterpret_cast<const uint4*>(sres->p) : nullptr;
     a.post_scale = fold ? nullptr : rt.d_post_scale;
-    a.post_shift = fold ? nullptr : rt.d_post_shift;
+    a.post_shift = fold ? nullptr : bias_view(ctx, rt.d_post_shift);
     a.head_w = rt.d_head_w;
-    a.head_b = rt.head_b;
+    a.head_b = ctx->scaled_pass ? 0.f : rt.head_b;
     if (L.head) a.head_out = dst.p;
     else if (ks.epi == EPI_PLAIN_F32) a.out_f32 = dst.p;
     else a.out = reinterpret_cast<uint4*>(dst.p);
@@ -1283,7 +1465,7 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
         // (measured, profiles/r03_persistent_ab.txt: +5 .. +60 % on the tiles of up to 96 channels, whose prologue is 10 - 20 % of
         // a tile; +-0 on the 128-channel 8-wave tiles, where the longer scalar state costs the K loop what the prologue gave)
         const bool want = ctx->persist_mode == 2 || (ctx->persist_mode == 1 && !ctx->lanes_on && nt >= 2LL * slots && ks.MT <= 96);
-        if (eligible && want) {
+        if (eligible && want && !ctx->rec_on) {
             const int wgs = ctx->persist_wgs > 0 ? ctx->persist_wgs : slots;
             a.n_tiles = (int)nt;
             grid = dim3((unsigned)std::max(8, wgs / 8 * 8), 1, 1);
@@ -1301,9 +1483,27 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
         if (a.res) bytes += 32.0 * a.cells_out * outpx;
         bytes += (double)n_cog * ks.stages(a.cells_in * std::max(a.KZ, 1)) * ks.W_STEP_BYTES * std::max(a.nphase, 1);
     }
+    // patch raster (conv_split.h, xcd_swizzle 2) for the one-workgroup-per-CU tiles of a launch of its own: the grid is padded to
+    // whole 8 x 4 blocks of tiles
+    if (ctx->raster && !ctx->rec_on && a.n_tiles == 0 && ks.WAVES == 8 && (long long)a.tiles_x * a.tiles_y >= 512) {
+        a.xcd_swizzle = 2;
+        grid = dim3((unsigned)((a.tiles_x + 7) / 8 * 8), (unsigned)((a.tiles_y + 3) / 4 * 4), (unsigned)gz);
+    }
+    if (ctx->rec_on) {
+        // a batched pass: recorded; rec_flush issues it together with the same layer's launch of the other images
+        RecOp op;
+        op.ks = &ks;
+        op.a = a;
+        op.a.n_tiles = (int)std::min<long long>((long long)a.tiles_x * a.tiles_y * gz, 0x7fffffff);
+        op.grid = grid;
+        op.cls = 0; op.flops = flops; op.bytes = bytes; op.key = ks.name;
+        ctx->rec[ctx->rec_cur].push_back(std::move(op));
+        return 0;
+    }
     prof_begin(ctx, 0, flops, ks.name, bytes);
     hipError_t e = ks.launch(a, grid, ctx->stream);
     prof_end(ctx);
+    ++ctx->n_launches;
     HIPCHK(ctx, e);
     return 0;
 }
@@ -1319,9 +1519,12 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         if (s2.pitch != s2.W || s2.ps != (long long)s2.H * s2.W) return fail(ctx, "2xf16 decoder needs a dense skip source");
         float* X = (float*)pool_alloc(ctx, (size_t)8 * s1.H * s1.W * sizeof(float));
         if (!X) return fail(ctx, "out of device memory");
-        prof_begin(ctx, 2, 0);
-        hipError_t e = launch_s2d_split(s2.p, X, 1, s1.H, s1.W, s2.H, s2.W, 2, ctx->d_flag, ctx->stream);
-        prof_end(ctx);
+        hipError_t e;
+        {
+            const float* sp_ = s2.p; unsigned* fl_ = ctx->d_flag;
+            const int h1 = s1.H, w1 = s1.W, h2 = s2.H, w2 = s2.W;
+            e = enqueue(ctx, [=](hipStream_t st) { return launch_s2d_split(sp_, X, 1, h1, w1, h2, w2, 2, fl_, st); });
+        }
         if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "s2d failed: %s", hipGetErrorString(e)); }
         SplitArgs a;
         memset(&a, 0, sizeof a);
@@ -1329,7 +1532,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.in2 = reinterpret_cast<const uint4*>(X);
         a.wpk = reinterpret_cast<const uint4*>(sp.d_w_low);
         a.wscale = sp.d_ws_low;
-        a.bias = rt.d_bias;
+        a.bias = bias_view(ctx, rt.d_bias);
         a.subpix_cout = L.cout;
         a.pad_x = a.pad_y = 1;
         a.out = reinterpret_cast<uint4*>(dst.p);
@@ -1357,16 +1560,19 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         if (s2.pitch != s2.W || s2.ps != (long long)s2.H * s2.W) return fail(ctx, "2xf16 decoder needs a dense skip source");
         Xs2d = (float*)pool_alloc(ctx, (size_t)8 * s1.D * s1.H * s1.W * sizeof(float));
         if (!Xs2d) return fail(ctx, "out of device memory");
-        prof_begin(ctx, 2, 0);
-        hipError_t e = launch_s2d_split(s2.p, Xs2d, s1.D, s1.H, s1.W, s2.H, s2.W, L.dims, ctx->d_flag, ctx->stream);
-        prof_end(ctx);
+        hipError_t e;
+        {
+            const float* sp_ = s2.p; unsigned* fl_ = ctx->d_flag;
+            const int d1 = s1.D, h1 = s1.H, w1 = s1.W, h2 = s2.H, w2 = s2.W, dims = L.dims;
+            e = enqueue(ctx, [=](hipStream_t st) { return launch_s2d_split(sp_, Xs2d, d1, h1, w1, h2, w2, dims, fl_, st); });
+        }
         if (e != hipSuccess) { pool_release(ctx, Xs2d); return fail(ctx, "s2d failed: %s", hipGetErrorString(e)); }
     } else if (sp.ki_skip_stem) {
         ConvArgs a;
         memset(&a, 0, sizeof a);
         a.in = s2.p;
         a.wpk = ph.d_w_skip;
-        a.bias = rt.d_bias;
+        a.bias = bias_view(ctx, rt.d_bias);
         a.out = dst.p;
         a.zeros = ctx->d_zeros;
         a.flag = ctx->d_flag;
@@ -1389,7 +1595,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
         a.in = reinterpret_cast<const uint4*>(s2.p);
         a.wpk = reinterpret_cast<const uint4*>(sp.d_w_skip);
         a.wscale = sp.d_ws_skip;
-        a.bias = rt.d_bias;
+        a.bias = bias_view(ctx, rt.d_bias);
         a.out = reinterpret_cast<uint4*>(dst.p);
         a.zeros = ctx->d_zeros;
         a.flag = ctx->d_flag;
@@ -1433,7 +1639,7 @@ static int run_conv_split_phases(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1
             a.in2 = reinterpret_cast<const uint4*>(Xs2d);
             a.cells_in = a.cells_in1 + 1;
             a.res = nullptr;
-            a.bias = rt.d_bias;
+            a.bias = bias_view(ctx, rt.d_bias);
             a.vol_srcmajor = sp.srcmajor ? 1 : 0;
         }
         a.Hin = a.H1 = s1.H; a.Win = a.W1 = s1.W;
@@ -1467,21 +1673,27 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     const int Hc = s1.H + 2 * L.pad - (L.k - 1), Wc = s1.W + 2 * L.pad - (L.k - 1);
     float* X = (float*)pool_alloc(ctx, (size_t)ncell * 8 * rows * Wc * sizeof(float));
     if (!X) return fail(ctx, "out of device memory");
-    prof_begin(ctx, 2, 0);
     // (2-D with a window: only the rows and columns the windowed conv reads -- output row y reads input rows y - pad .. y + pad)
     const Rect& w = dst.need;
-    hipError_t e = (w.on && L.dims == 2)
-        ? launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream, (size_t)std::max(0, w.y0 - L.pad),
-                              (size_t)std::min(s1.H, w.y1 + L.pad), w.x0, std::min(Wc, (w.x1 + 1) & ~1))
-        : launch_shiftx_split(s1.p, X, L.k, L.pad, rows, s1.W, Wc, ctx->d_flag, ctx->stream);
-    prof_end(ctx);
+    hipError_t e;
+    {
+        const float* sp_ = s1.p; unsigned* fl_ = ctx->d_flag;
+        const int k = L.k, pad = L.pad, W1 = s1.W;
+        if (w.on && L.dims == 2) {
+            const size_t r0 = (size_t)std::max(0, w.y0 - L.pad), r1 = (size_t)std::min(s1.H, w.y1 + L.pad);
+            const int c0 = w.x0, c1 = std::min(Wc, (w.x1 + 1) & ~1);
+            e = enqueue(ctx, [=](hipStream_t st) { return launch_shiftx_split(sp_, X, k, pad, rows, W1, Wc, fl_, st, r0, r1, c0, c1); });
+        } else {
+            e = enqueue(ctx, [=](hipStream_t st) { return launch_shiftx_split(sp_, X, k, pad, rows, W1, Wc, fl_, st); });
+        }
+    }
     if (e != hipSuccess) { pool_release(ctx, X); return fail(ctx, "shiftx failed: %s", hipGetErrorString(e)); }
     SplitArgs a;
     memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const uint4*>(X);
     a.wpk = reinterpret_cast<const uint4*>(rt.d_wsplit);
     a.wscale = rt.d_wscale;
-    a.bias = rt.d_bias;
+    a.bias = bias_view(ctx, rt.d_bias);
     a.out = reinterpret_cast<uint4*>(dst.p);
     a.zeros = ctx->d_zeros;
     a.flag = ctx->d_flag;
@@ -1537,15 +1749,17 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     if (!rc) {
         // (labelled: an HBM-bound kernel whose bandwidth bench.py reports -- reads k planes of Wp columns, writes one of W)
         const double ss_rows = w.on ? (double)(w.y1 - w.y0) : (double)rows, ss_cols = w.on ? (double)(w.x1 - w.x0) : (double)dst.W;
-        prof_begin(ctx, 2, 0, "shiftsum (last conv: sum of the k column-kernel planes + bias + un-normalisation)",
-                   4.0 * ss_rows * ((double)L.k * (ss_cols + 2 * L.pad) + ss_cols));
         // (a residual of the output's own size -- UDenoiseNet3: x - dec1(h), weights negated -- is added here, in fp32)
         const float* resp = sres ? sres->p : nullptr;
-        hipError_t e = w.on ? launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out,
-                                              ctx->stream, (size_t)w.y0, (size_t)w.y1, w.x0, w.x1, resp)
-                            : launch_shiftsum(Y, dst.p, L.k, rows, dst.W, Wp, L.b_off >= 0 ? rt.bias0 : 0.f, d_nrm, norm_out, ctx->stream,
-                                              0, (size_t)-1, 0, 0x7fffffff, resp);
-        prof_end(ctx);
+        float* dp_ = dst.p;
+        const int k = L.k, Wd = dst.W;
+        const float b0 = L.b_off >= 0 ? rt.bias0 : 0.f;
+        const size_t r0 = w.on ? (size_t)w.y0 : 0, r1 = w.on ? (size_t)w.y1 : (size_t)-1;
+        const int c0 = w.on ? w.x0 : 0, c1 = w.on ? w.x1 : 0x7fffffff;
+        hipError_t e = enqueue(ctx, 2, 0.0, "shiftsum (last conv: sum of the k column-kernel planes + bias + un-normalisation)",
+                               4.0 * ss_rows * ((double)L.k * (ss_cols + 2 * L.pad) + ss_cols), [=](hipStream_t st) {
+                                   return launch_shiftsum(Y, dp_, k, rows, Wd, Wp, b0, d_nrm, norm_out, st, r0, r1, c0, c1, resp);
+                               });
         if (e != hipSuccess) rc = fail(ctx, "shiftsum failed: %s", hipGetErrorString(e));
     }
     pool_release(ctx, Y);
@@ -1560,11 +1774,15 @@ static float* slot_as(tpz_ctx* ctx, Slot& s, bool want_split) {
     const size_t c_alloc = want_split ? split_cells(s.C) * 8 : (size_t)s.C;
     float* q = (float*)pool_alloc(ctx, c_alloc * s.D * s.H * s.W * sizeof(float));
     if (!q) return nullptr;
-    prof_begin(ctx, 2, 0);
     // cells are [c/8][D*H*W]: a volume converts as an image of D*H rows
-    hipError_t e = want_split ? launch_to_split(s.p, q, s.C, s.D * s.H, s.W, ctx->d_flag, ctx->stream)
-                              : launch_from_split(s.p, q, s.C, s.D * s.H, s.W, ctx->stream);
-    prof_end(ctx);
+    hipError_t e;
+    {
+        const float* sp_ = s.p; unsigned* fl_ = ctx->d_flag;
+        const int C = s.C, R = s.D * s.H, W = s.W;
+        e = enqueue(ctx, [=](hipStream_t st) {
+            return want_split ? launch_to_split(sp_, q, C, R, W, fl_, st) : launch_from_split(sp_, q, C, R, W, st);
+        });
+    }
     if (e != hipSuccess) { pool_release(ctx, q); return nullptr; }
     s.alt = q;
     return q;
@@ -1578,12 +1796,12 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.in = s1.p;
     a.in2 = s2 ? s2->p : nullptr;
     a.wpk = rt.d_wpk;
-    a.bias = rt.d_bias;
+    a.bias = bias_view(ctx, rt.d_bias);
     a.res = sres ? sres->p : nullptr;
     a.post_scale = rt.d_post_scale;
-    a.post_shift = rt.d_post_shift;
+    a.post_shift = bias_view(ctx, rt.d_post_shift);
     a.head_w = rt.d_head_w;
-    a.head_b = rt.head_b;
+    a.head_b = ctx->scaled_pass ? 0.f : rt.head_b;
     a.nrm = d_nrm;
     a.zeros = ctx->d_zeros;
     a.norm_out = d_nrm ? norm_out : 0;
@@ -1620,9 +1838,11 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
         if (launch_mfma(ctx, ki, a, rt.n_cog, flops)) return 1;
     } else {
         if (s1.D != geo.D || s1.H != geo.H || s1.W != geo.W) return fail(ctx, "direct conv cannot upsample");
-        prof_begin(ctx, 1, a.wy1 > 0 ? flops * (a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout) : flops);
-        hipError_t e = launch_conv_direct(a, rt.d_wpk, L.k, L.dims == 3 ? L.k : 1, L.dil, ctx->stream);
-        prof_end(ctx);
+        const ConvArgs ac = a;
+        const float* wp_ = rt.d_wpk;
+        const int k = L.k, kz = L.dims == 3 ? L.k : 1, dil = L.dil;
+        hipError_t e = enqueue(ctx, 1, a.wy1 > 0 ? flops * (a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout) : flops, nullptr,
+                               0.0, [=](hipStream_t st) { return launch_conv_direct(ac, wp_, k, kz, dil, st); });
         HIPCHK(ctx, e);
     }
     return 0;
@@ -1818,9 +2038,12 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             dst.split = true;
             dst.alt = nullptr;
             dst.owned = (i != nl - 1);
-            prof_begin(ctx, 2, 0);
-            hipError_t e = launch_maxpoolz_split(src.p, dst.p, src.C, src.D, src.H, src.W, ctx->stream);
-            prof_end(ctx);
+            hipError_t e;
+            {
+                const float* sp_ = src.p; float* dp_ = dst.p;
+                const int C = src.C, Dd = src.D, Hh = src.H, Ww = src.W;
+                e = enqueue(ctx, [=](hipStream_t st) { return launch_maxpoolz_split(sp_, dp_, C, Dd, Hh, Ww, st); });
+            }
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else if (L.op == TPZ_OP_MAXPOOL2 && s1.pooled) {
             // already pooled by the producing conv: the slot changes hands
@@ -1844,10 +2067,14 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             dst.split = sp;
             dst.alt = nullptr;
             dst.owned = (i != nl - 1);
-            prof_begin(ctx, 2, 0);
-            hipError_t e = sp ? launch_maxpool2_split(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream)
-                              : launch_maxpool2(src_p, dst.p, Cs, Ds, Hs, Ws, L.dims, ctx->stream);
-            prof_end(ctx);
+            hipError_t e;
+            {
+                float* dp_ = dst.p;
+                const int dims = L.dims;
+                e = enqueue(ctx, [=](hipStream_t st) {
+                    return sp ? launch_maxpool2_split(src_p, dp_, Cs, Ds, Hs, Ws, dims, st) : launch_maxpool2(src_p, dp_, Cs, Ds, Hs, Ws, dims, st);
+                });
+            }
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else if (L.op == TPZ_OP_MAXPOOL) {
             if (s1.pitch != s1.W || s1.ps != (long long)s1.H * s1.W) { rc = fail(ctx, "maxpool needs a dense input"); break; }
@@ -1865,9 +2092,12 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
             dst.split = sp;
             dst.alt = nullptr;
             dst.owned = (i != nl - 1);
-            prof_begin(ctx, 2, 0);
-            hipError_t e = launch_maxpoolk(src_p, dst.p, Cs, Ds, Hs, Ws, L.k, L.dil, L.dims, sp, ctx->stream);
-            prof_end(ctx);
+            hipError_t e;
+            {
+                float* dp_ = dst.p;
+                const int k = L.k, dil = L.dil, dims = L.dims;
+                e = enqueue(ctx, [=](hipStream_t st) { return launch_maxpoolk(src_p, dp_, Cs, Ds, Hs, Ws, k, dil, dims, sp, st); });
+            }
             if (e != hipSuccess) rc = fail(ctx, "maxpool launch failed: %s", hipGetErrorString(e));
         } else {
             rc = fail(ctx, "layer %d: unknown op %d", i, L.op);
@@ -1924,6 +2154,7 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
         hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, NMS_COUNTERS * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flag, 16) != hipSuccess || hipHostMalloc((void**)&ctx->h_flag, 16) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_absmax, 16) != hipSuccess || hipMemset(ctx->d_absmax, 0, 16) != hipSuccess ||
         hipMalloc((void**)&ctx->d_zeros, 256) != hipSuccess || hipMemset(ctx->d_zeros, 0, 256) != hipSuccess) {
         delete ctx;
         return fail(nullptr, "tpz_ctx_create: hipMalloc failed");
@@ -1939,6 +2170,8 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->io_stage) tpz_stage_free(ctx->io_stage);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
+    for (auto& rp : ctx->rec_pools)
+        for (auto& b : rp) (void)hipFree(b.p);
     for (auto& ln : ctx->lanes) {
         for (auto& b : ln.pool) (void)hipFree(b.p);
         if (ln.d_part) (void)hipFree(ln.d_part);
@@ -1951,6 +2184,7 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_zeros);
     (void)hipFree(ctx->d_flag);
+    (void)hipFree(ctx->d_absmax);
     (void)hipHostFree(ctx->h_flag);
     for (auto& e : ctx->split_plans) (void)hipFree(e.d);
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
@@ -1977,6 +2211,37 @@ static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const
 int tpz_model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
                    tpz_model** out) {
     return model_load(ctx, layers, n_layers, h_blob, n_floats, {1}, out);    // slot 0 = the 1-channel input
+}
+
+// Moves every bias-like vector of the model (each chan_pad-ed) into ONE device array and allocates a second one of the same size:
+// a range-scaled pass (tpz_model_forward) writes 2^-s * arena there with one small kernel and reads its biases `bias_shift`
+// floats further on.
+static int build_bias_arena(tpz_ctx* ctx, tpz_model* m) {
+    std::vector<std::pair<float**, size_t>> vecs;
+    for (LayerRT& rt : m->layers) {
+        if (rt.L.op != TPZ_OP_CONV) continue;
+        const size_t n = chan_pad((size_t)rt.L.cout);
+        if (rt.d_bias) vecs.push_back({&rt.d_bias, n});
+        if (rt.d_post_shift) vecs.push_back({&rt.d_post_shift, n});
+        if (rt.d_bias_fold) vecs.push_back({&rt.d_bias_fold, n});
+    }
+    size_t total = 0;
+    for (auto& v : vecs) total += v.second;
+    if (total == 0) return 0;
+    float *arena = nullptr, *scaled = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&arena, total * sizeof(float)));
+    m->dev_allocs.push_back(arena);
+    HIPCHK(ctx, hipMalloc((void**)&scaled, total * sizeof(float)));
+    m->dev_allocs.push_back(scaled);
+    size_t off = 0;
+    for (auto& v : vecs) {
+        HIPCHK(ctx, hipMemcpy(arena + off, *v.first, v.second * sizeof(float), hipMemcpyDeviceToDevice));
+        *v.first = arena + off;              // (the vector's first home stays in dev_allocs and is freed with the model)
+        off += v.second;
+    }
+    HIPCHK(ctx, hipMemcpy(scaled, arena, total * sizeof(float), hipMemcpyDeviceToDevice));
+    m->d_bias_arena = arena; m->d_bias_scaled = scaled; m->n_bias_arena = total;
+    return 0;
 }
 
 // preset_chan: channels of the externally provided slots (slot 0, and tpz_conv's extra sources)
@@ -2008,6 +2273,7 @@ static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const
         chan[L.dst] = L.op == TPZ_OP_CONV ? (L.head ? 1 : L.cout) : c1;
     }
     if (preset_chan.size() == 1 && prepare_split(ctx, m, h_blob)) { tpz_model_free(m); return 1; }
+    if (preset_chan.size() == 1 && build_bias_arena(ctx, m)) { tpz_model_free(m); return 1; }
     *out = m;
     return 0;
 }
@@ -2067,6 +2333,66 @@ static bool split_volume_fits(const tpz_model* m, int D, int H, int W) {
     return split_cells((int)cmax) * (size_t)D * H * W * 16 < ((size_t)1 << 32) - 16;
 }
 
+// One image through the program -- whole, or, a 2-D image above the tiling limit through a size-preserving network, TILE by
+// tile: `topaz extract` scores any image that fits memory (topaz/extract.py:247-249), while the kernels address a chunk of cells
+// with 32-bit byte offsets (< 4 GiB: ~11 500^2 pixels) and a whole-image pass of a large detector frame holds every activation at
+// full size.  The filled network is translation-equivariant with a finite receptive field: a tile's outputs are those of the
+// network run on the tile grown by that halo (clipped at the image borders, where the layers' own zero padding applies as it
+// does on the whole image), minus the halo ring.  Every kept logit is computed by the same instructions on the same operands as
+// in a whole-image pass: bit-identical (tests/test_gpu_scoring.py::test_internal_tiling_is_bit_identical).
+static int model_halo(const tpz_model* m) {
+    int h = 0;
+    for (const LayerRT& rt : m->layers) {
+        const tpz_layer& L = rt.L;
+        if (L.op == TPZ_OP_CONV) h += std::max(L.pad, L.dil * (L.k - 1) - L.pad);        // (an upper bound: every layer counted)
+        else if (L.op == TPZ_OP_MAXPOOL) h += L.dil * (L.k - 1);
+        else return -1;                                                                   // (pooling by 2: not equivariant)
+    }
+    return (h + 1) & ~1;
+}
+
+static int run_image(tpz_model* m, float* x, int D, int H, int W, float* out, int Co, int Do, int Ho, int Wo, bool split) {
+    tpz_ctx* ctx = m->ctx;
+    const int halo = (D == 1 && Ho == H && Wo == W) ? model_halo(m) : -1;
+    if (halo < 0 || (long long)H * W <= ctx->tile_limit_px) {
+        std::vector<Slot> slots(m->n_slots);
+        set_dense(slots[0], x, 1, D, H, W);
+        return run_program(m, slots, out, nullptr, split);
+    }
+    const int T = std::max(16, ctx->tile_size);
+    for (int ty = 0; ty < H; ty += T)
+        for (int tx = 0; tx < W; tx += T) {
+            const int y0 = std::max(0, ty - halo), y1 = std::min(H, ty + T + halo);
+            const int x0 = std::max(0, tx - halo), x1 = std::min(W, tx + T + halo);
+            const int wh = y1 - y0, ww = x1 - x0, th = std::min(T, H - ty), tw = std::min(T, W - tx);
+            float* xt = (float*)pool_alloc(ctx, (size_t)wh * ww * sizeof(float));
+            float* ot = (float*)pool_alloc(ctx, (size_t)Co * wh * ww * sizeof(float));
+            int rc = (!xt || !ot) ? fail(ctx, "out of device memory") : 0;
+            if (!rc) {
+                const float* src = x + (size_t)y0 * W + x0;
+                const hipError_t e = enqueue(ctx, [=](hipStream_t st) { return launch_copy_box(src, 0, W, xt, 0, ww, 1, wh, ww, st); });
+                if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
+            }
+            if (!rc) {
+                std::vector<Slot> slots(m->n_slots);
+                set_dense(slots[0], xt, 1, 1, wh, ww);
+                rc = run_program(m, slots, ot, nullptr, split);
+            }
+            if (!rc) {
+                const float* src = ot + (size_t)(ty - y0) * ww + (tx - x0);
+                float* dst = out + (size_t)ty * W + tx;
+                const hipError_t e = enqueue(ctx, [=](hipStream_t st) {
+                    return launch_copy_box(src, (long long)wh * ww, ww, dst, (long long)H * W, W, Co, th, tw, st);
+                });
+                if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
+            }
+            if (xt) pool_release(ctx, xt);
+            if (ot) pool_release(ctx, ot);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
 int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int W, float* d_out) {
     if (!m || !d_in || !d_out) return fail(m ? m->ctx : nullptr, "tpz_model_forward: NULL argument");
     tpz_ctx* ctx = m->ctx;
@@ -2082,19 +2408,44 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
         if (m->split_ok && !ctx->exact && split_volume_fits(m, D, H, W)) {
             // 2xf16 path; an activation beyond the f16 range (flag) sends this image to the fp32 kernels instead
             HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned), ctx->stream));
-            std::vector<Slot> slots(m->n_slots);
-            set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
-            if (run_program(m, slots, out_b, nullptr, true)) return 1;
+            float* x_b = const_cast<float*>(d_in) + (size_t)b * D * H * W;
+            // RANGE SCALING (scoring networks = programs ending in the linear head): `topaz extract` does not normalise its
+            // input (extract.py:234-249), and a raw-count micrograph would leave the f16 range in the stem.  The network is
+            // positively homogeneous in (input, biases): it runs on x * 2^-s with its biases scaled alike and the logits are
+            // multiplied back -- exact, powers of two; s = 0 for an image within +-32 (kernels_misc.hip launch_range_fit).
+            const bool scaled = ctx->range_scaling && m->layers.back().L.op == TPZ_OP_CONV && m->layers.back().L.head &&
+                                m->d_bias_scaled != nullptr;
+            float *xs = nullptr, *rng = nullptr;
+            if (scaled) {
+                const size_t n_in = (size_t)D * H * W;
+                rng = next_nrm(ctx);
+                xs = (float*)pool_alloc(ctx, n_in * sizeof(float));
+                if (!xs) return fail(ctx, "out of device memory");
+                hipError_t e = enqueue(ctx, [=](hipStream_t st) {
+                    return launch_range_fit(x_b, n_in, 32.f, ctx->d_absmax, rng, m->d_bias_arena, m->d_bias_scaled, m->n_bias_arena, st);
+                });
+                if (e == hipSuccess) e = enqueue(ctx, [=](hipStream_t st) { return launch_affine_dev(x_b, D, H, W, (long long)H * W, W, rng, xs, st); });
+                if (e != hipSuccess) { pool_release(ctx, xs); return fail(ctx, "range scaling failed: %s", hipGetErrorString(e)); }
+                x_b = xs;
+                ctx->bias_shift = m->d_bias_scaled - m->d_bias_arena;
+                ctx->scaled_pass = true;
+            }
+            const int rc = run_image(m, x_b, D, H, W, out_b, Co, Do, Ho, Wo, true);
+            ctx->bias_shift = 0;
+            ctx->scaled_pass = false;
+            if (xs) pool_release(ctx, xs);
+            if (rc) return 1;
+            if (scaled) {
+                const size_t n_out = (size_t)Co * Do * Ho * Wo;
+                const float hb = m->layers.back().head_b;
+                HIPCHK(ctx, enqueue(ctx, [=](hipStream_t st) { return launch_unscale(out_b, n_out, rng, hb, st); }));
+            }
             HIPCHK(ctx, hipMemcpyAsync(ctx->h_flag, ctx->d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             done = (*ctx->h_flag == 0);
             if (done) ++m->n_split; else ++m->n_fallback;
         }
-        if (!done) {
-            std::vector<Slot> slots(m->n_slots);
-            set_dense(slots[0], const_cast<float*>(d_in) + (size_t)b * D * H * W, 1, D, H, W);
-            if (run_program(m, slots, out_b, nullptr)) return 1;
-        }
+        if (!done && run_image(m, const_cast<float*>(d_in) + (size_t)b * D * H * W, D, H, W, out_b, Co, Do, Ho, Wo, false)) return 1;
     }
     return 0;
 }
@@ -2103,9 +2454,17 @@ int tpz_ctx_set_lanes(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     if (on < 0 || on > N_LANES) return fail(ctx, "tpz_ctx_set_lanes: 0 (off), 1 (on, two lanes) or a lane count up to %d", (int)N_LANES);
     ctx->lanes_enabled = on != 0;
-    if (on >= 2) ctx->n_lanes = on;
+    if (on >= 1) ctx->n_lanes = on == 1 ? 2 : on;
     return 0;
 }
+
+int tpz_ctx_set_batch(tpz_ctx* ctx, int n) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    if (n < 0 || n > (int)SPLIT_MULTI_MAX) return fail(ctx, "tpz_ctx_set_batch: 0 (off) or up to %d images per launch", (int)SPLIT_MULTI_MAX);
+    ctx->batch = n == 1 ? 0 : n;
+    return 0;
+}
+long long tpz_prof_launches(tpz_ctx* ctx) { return ctx ? ctx->n_launches : 0; }
 
 int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups) {
     if (!ctx || mode < 0 || mode > 2 || workgroups < 0) return fail(ctx, "tpz_ctx_set_persist: bad arguments");
@@ -2116,6 +2475,25 @@ int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups) {
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on) {
     if (!ctx) return 1;
     ctx->roi_enabled = on != 0;
+    return 0;
+}
+
+int tpz_ctx_set_tiling(tpz_ctx* ctx, long long limit_px, int tile) {
+    if (!ctx || limit_px < 1 || tile < 16) return fail(ctx, "tpz_ctx_set_tiling: limit_px >= 1, tile >= 16");
+    ctx->tile_limit_px = limit_px;
+    ctx->tile_size = tile;
+    return 0;
+}
+
+int tpz_ctx_set_raster(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    ctx->raster = on != 0;
+    return 0;
+}
+
+int tpz_ctx_set_range(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    ctx->range_scaling = on != 0;
     return 0;
 }
 
@@ -2130,6 +2508,14 @@ int tpz_model_split_stats(tpz_model* m, int* eligible, long long* split_runs, lo
     if (eligible) *eligible = m->split_ok ? 1 : 0;
     if (split_runs) *split_runs = m->n_split;
     if (fp32_reruns) *fp32_reruns = m->n_fallback;
+    return 0;
+}
+
+int tpz_model_split_layers(tpz_model* m, int* n_conv, int* n_split, char* off_path, int off_path_len) {
+    if (!m) return fail(nullptr, "model is NULL");
+    if (n_conv) *n_conv = m->n_conv;
+    if (n_split) *n_split = m->n_conv_split;
+    if (off_path && off_path_len > 0) snprintf(off_path, (size_t)off_path_len, "%s", m->off_path.c_str());
     return 0;
 }
 
@@ -2203,18 +2589,19 @@ static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, in
                           const float* d_g = nullptr, bool split = false, const Rect* keep = nullptr) {
     tpz_ctx* ctx = m->ctx;
     float* nrm = next_nrm(ctx);
-    prof_begin(ctx, 2, 0);
-    hipError_t e = launch_meanstd(view.p, view.D, view.H, view.W, view.ps, view.pitch, /*unbiased*/ 1, mode,
-                                  d_g, ctx->d_part, PART_BLOCKS, nrm, ctx->stream);
-    prof_end(ctx);
+    const float* vp_ = view.p;
+    const int vD = view.D, vH = view.H, vW = view.W, vpitch = view.pitch;
+    const long long vps = view.ps;
+    double* part = ctx->d_part;
+    hipError_t e = enqueue(ctx, [=](hipStream_t st) {
+        return launch_meanstd(vp_, vD, vH, vW, vps, vpitch, /*unbiased*/ 1, mode, d_g, part, PART_BLOCKS, nrm, st);
+    });
     HIPCHK(ctx, e);
     // (x - mu)/std once, into a dense buffer every reader of slot 0 (first conv, dec1 concat) DMA-loads
     const size_t n = (size_t)view.D * view.H * view.W;
     float* xn = (float*)pool_alloc(ctx, n * sizeof(float));
     if (!xn) return fail(ctx, "out of device memory");
-    prof_begin(ctx, 2, 0);
-    e = launch_affine_dev(view.p, view.D, view.H, view.W, view.ps, view.pitch, nrm, xn, ctx->stream);
-    prof_end(ctx);
+    e = enqueue(ctx, [=](hipStream_t st) { return launch_affine_dev(vp_, vD, vH, vW, vps, vpitch, nrm, xn, st); });
     if (e != hipSuccess) { pool_release(ctx, xn); return fail(ctx, "affine_dev failed: %s", hipGetErrorString(e)); }
     std::vector<Slot> slots(m->n_slots);
     set_dense(slots[0], xn, 1, view.D, view.H, view.W);
@@ -2232,11 +2619,26 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
         set_dense(v, const_cast<float*>(d_in), 1, 1, H, W);
         return denoise_region(m, v, d_out, 1, nullptr, split);
     }
-    if (lanes_begin(ctx)) return 1;
-    int rc_all = 0, n_patch = 0;
+    // the patches are independent: on the 2xf16 path they run in batches (the same layer of `batch` patches in one launch:
+    // rec_begin / rec_flush), otherwise alternating on the patch lanes
+    const bool batched = split && ctx->batch >= 2;
+    if (!batched && lanes_begin(ctx)) return 1;
+    int rc_all = 0, n_patch = 0, slot = 0, slots_left = 0;
     for (int i = 0; i < H && !rc_all; i += patch)
         for (int j = 0; j < W && !rc_all; j += patch) {
-            lane_enter(ctx, n_patch++);
+            if (batched) {
+                if (slots_left == 0) {
+                    if (ctx->rec_on && rec_flush(ctx)) { rc_all = 1; break; }
+                    rec_begin(ctx);
+                    slots_left = ctx->batch;
+                    slot = 0;
+                }
+                rec_select(ctx, slot++);
+                --slots_left;
+                ++n_patch;
+            } else {
+                lane_enter(ctx, n_patch++);
+            }
             const int si = std::max(0, i - pad), ei = std::min(H, i + patch + pad);
             const int sj = std::max(0, j - pad), ej = std::min(W, j + patch + pad);
             const int ph = ei - si, pw = ej - sj;
@@ -2253,17 +2655,19 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
             keep.y0 = oi; keep.x0 = oj; keep.y1 = oi + ch; keep.x1 = oj + cw; keep.on = true;
             int rc = denoise_region(m, v, tmp, 1, nullptr, split, &keep);
             if (rc == 0) {
-                prof_begin(ctx, 2, 0);
-                hipError_t e = launch_copy_box(tmp + (size_t)oi * pw + oj, 0, pw, d_out + (size_t)i * W + j, 0, W, 1, ch,
-                                               cw, ctx->stream);
-                prof_end(ctx);
+                const float* src_ = tmp + (size_t)oi * pw + oj;
+                float* dst_ = d_out + (size_t)i * W + j;
+                hipError_t e = enqueue(ctx, [=](hipStream_t st) { return launch_copy_box(src_, 0, pw, dst_, 0, W, 1, ch, cw, st); });
                 if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
             }
             pool_release(ctx, tmp);
             if (rc) rc_all = rc;
         }
     const std::string err = ctx->err;
-    if (lanes_end(ctx) && !rc_all) rc_all = 1;
+    if (batched) {
+        if (ctx->rec_on && !rc_all && rec_flush(ctx)) rc_all = 1;
+        rec_abort(ctx);
+    } else if (lanes_end(ctx) && !rc_all) rc_all = 1;
     if (rc_all && !err.empty()) ctx->err = err;
     return rc_all;
 }
@@ -2300,46 +2704,68 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     HIPCHK(ctx, launch_meanstd(d_in, D, H, W, (long long)H * W, W, 0, 0, nullptr, ctx->d_part, PART_BLOCKS, g, ctx->stream));
     const int d = patch + 2 * pad;
     const size_t tn = (size_t)d * d * d;
-    if (lanes_begin(ctx)) return 1;
-    const int n_lanes = ctx->lanes_on ? ctx->lanes_live : 1;
-    float *tiles[N_LANES] = {}, *touts[N_LANES] = {};
+    // the tiles are independent: batches of `batch` tiles on the 2xf16 path (as the patches of denoise_2d_pass), else the lanes
+    const bool batched = split && ctx->batch >= 2;
+    if (!batched && lanes_begin(ctx)) return 1;
+    enum { MAX_INST = N_LANES > (int)SPLIT_MULTI_MAX ? (int)N_LANES : (int)SPLIT_MULTI_MAX };
+    const int n_lanes = batched ? ctx->batch : ctx->lanes_on ? ctx->lanes_live : 1;
+    float *tiles[MAX_INST] = {}, *touts[MAX_INST] = {};
     int rc = 0;
+    auto inst_enter = [&](int l) {
+        if (batched) { ctx->rec_cur = l; ctx->pool_cur = &ctx->rec_pools[l]; }
+        else lane_enter(ctx, l);
+    };
     for (int l = 0; l < n_lanes; ++l) {
-        lane_enter(ctx, l);
+        inst_enter(l);
         tiles[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
         touts[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
         if (!tiles[l] || !touts[l]) rc = fail(ctx, "out of device memory");
     }
-    int n_tile = 0, tile_index = 0;
+    int n_tile = 0, tile_index = 0, slot = 0, slots_left = 0;
     for (int i = 0; i < D && !rc; i += patch)
         for (int j = 0; j < H && !rc; j += patch)
             for (int k = 0; k < W && !rc; k += patch) {
                 if (tile_index++ % n_shards != shard) continue;        // another rank's tile
-                const int l = n_tile++ % n_lanes;
-                lane_enter(ctx, l);
+                int l = n_tile++ % n_lanes;
+                if (batched) {
+                    if (slots_left == 0) {
+                        if (ctx->rec_on && rec_flush(ctx)) { rc = 1; break; }
+                        rec_begin(ctx);
+                        slots_left = ctx->batch;
+                        slot = 0;
+                    }
+                    l = slot++;
+                    --slots_left;
+                }
+                inst_enter(l);
                 float *tile = tiles[l], *tout = touts[l];
-                prof_begin(ctx, 2, 0);
-                hipError_t e = launch_extract_tile3d(d_in, D, H, W, i - pad, j - pad, k - pad, d, g, tile, ctx->stream);
-                prof_end(ctx);
+                hipError_t e = enqueue(ctx, [=](hipStream_t st) {
+                    return launch_extract_tile3d(d_in, D, H, W, i - pad, j - pad, k - pad, d, g, tile, st);
+                });
                 if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
                 Slot tv;
                 set_dense(tv, tile, 1, d, d, d);
                 rc = denoise_region(m, tv, tout, 2, g, split);
                 if (rc) break;
                 const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
-                prof_begin(ctx, 2, 0);
-                e = launch_copy_box(tout + ((size_t)pad * d + pad) * d + pad, (long long)d * d, d,
-                                    d_out + ((size_t)i * H + j) * W + k, (long long)H * W, W, pz, py, px, ctx->stream);
-                prof_end(ctx);
+                {
+                    const float* src_ = tout + ((size_t)pad * d + pad) * d + pad;
+                    float* dst_ = d_out + ((size_t)i * H + j) * W + k;
+                    e = enqueue(ctx, [=](hipStream_t st) {
+                        return launch_copy_box(src_, (long long)d * d, d, dst_, (long long)H * W, W, pz, py, px, st);
+                    });
+                }
                 if (e != hipSuccess) rc = fail(ctx, "copy_box failed: %s", hipGetErrorString(e));
             }
+    const std::string err = ctx->err;
+    if (batched && ctx->rec_on && !rc && rec_flush(ctx)) rc = 1;
     for (int l = 0; l < n_lanes; ++l) {
-        lane_enter(ctx, l);
+        inst_enter(l);
         if (tiles[l]) pool_release(ctx, tiles[l]);
         if (touts[l]) pool_release(ctx, touts[l]);
     }
-    const std::string err = ctx->err;
-    if (lanes_end(ctx) && !rc) rc = 1;
+    if (batched) rec_abort(ctx);
+    else if (lanes_end(ctx) && !rc) rc = 1;
     if (rc && !err.empty()) ctx->err = err;
     return rc;
 }

@@ -391,7 +391,14 @@ def extract_particles(paths: List[str], model, device: int, batch_size: int, thr
     rank, local_rank, world = parallel.init_from_env()
     if world > 1:
         device = local_rank
-    paths = list(paths) if len(paths) else list(stream_inputs(sys.stdin))
+    if len(paths):
+        paths = list(paths)
+    elif os.environ.get('TOPAZ_AMD_INPUT_LIST'):
+        # a rank of `topaz extract --gpus N < list`: the launcher read stdin once for all ranks (main.py)
+        with open(os.environ['TOPAZ_AMD_INPUT_LIST']) as f:
+            paths = list(stream_inputs(f))
+    else:
+        paths = list(stream_inputs(sys.stdin))
     mine = parallel.shard_indices(len(paths), rank, world)
     maps = score_images(model, [paths[i] for i in mine], device=device, patch_size=patch_size, batch_size=batch_size,
                         keep_on_device=True)

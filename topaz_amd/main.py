@@ -24,11 +24,14 @@ def main(argv=None):
         # command shards its input list over the ranks (parallel.shard_indices), extract gathers the pick tables
         from . import parallel
         cmd = [sys.executable, '-m', 'topaz_amd'] + list(sys.argv[1:] if argv is None else argv)
-        listfile = None
-        if hasattr(args, 'paths') and len(args.paths) == 0:
+        listfile, env = None, None
+        if args.func is extract.main and len(args.paths) == 0:
             # the input list comes from stdin (extract.py:352 of this package; topaz/extract.py:270): N ranks sharing one stdin
             # would each consume a different part of it and take THAT for the whole list.  The launcher reads it once and
-            # hands every rank the same list through an @file argument (argparse expands it: main.py:55 upstream).
+            # hands every rank the same list OUT OF BAND (a file named in TOPAZ_AMD_INPUT_LIST, read by extract_particles when
+            # it has no paths): names beginning with '-' or '@', or a command line ending in a variadic option, cannot be
+            # re-interpreted by the ranks' argument parsers.
+            import os
             import tempfile
             names = [ln.strip() for ln in sys.stdin if ln.strip()]
             if not names:
@@ -37,9 +40,9 @@ def main(argv=None):
             fd.write('\n'.join(names) + '\n')
             fd.close()
             listfile = fd.name
-            cmd.append('@' + listfile)
+            env = dict(os.environ, TOPAZ_AMD_INPUT_LIST=listfile)
         try:
-            return parallel.launch_local_ranks(n, cmd)
+            return parallel.launch_local_ranks(n, cmd, env=env)
         finally:
             if listfile:
                 import os

@@ -58,7 +58,29 @@ def _parse_cpulist(text: str) -> List[int]:
     return out
 
 
-def cpu_sets_for_ranks(n: int, sysfs: str = '/sys', allowed: Optional[Sequence[int]] = None) -> List[List[int]]:
+_VISIBLE_VARS = ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'GPU_DEVICE_ORDINAL')
+
+
+def gpu_numa_nodes(n: int, sysfs: str = '/sys') -> Optional[List[int]]:
+    """NUMA node of HIP device 0 .. n-1 as HIP itself enumerates them: the device's PCI address (torch's device properties) ->
+    /sys/bus/pci/devices/<domain:bus:device.0>/numa_node.  Unlike the DRM card order this holds under *_VISIBLE_DEVICES
+    subsets and partition modes.  None when it cannot be resolved (no GPU runtime in this process, properties without a PCI
+    address, no sysfs entry) -- the caller then falls back.  Only called in rank processes, which initialise HIP anyway."""
+    try:
+        if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+            return None
+        nodes = []
+        for r in range(n):
+            pr = torch.cuda.get_device_properties(r)
+            bdf = f'{int(getattr(pr, "pci_domain_id", 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0'
+            nodes.append(int(open(os.path.join(sysfs, 'bus/pci/devices', bdf, 'numa_node')).read().strip()))
+        return nodes
+    except (AttributeError, OSError, ValueError, RuntimeError):
+        return None
+
+
+def cpu_sets_for_ranks(n: int, sysfs: str = '/sys', allowed: Optional[Sequence[int]] = None,
+                       nodes: Optional[Sequence[int]] = None) -> List[List[int]]:
     """Host placement of n rank processes on one node: rank r gets CPUs of the NUMA node GPU r hangs off (the amdgpu render
     devices of /sys/class/drm in card order, their device/numa_node, that node's cpulist), the GPUs of one node sharing its CPUs
     in equal contiguous slices -- each rank's launch thread (~700 kernel launches per micrograph) and reader thread then stay
@@ -79,19 +101,13 @@ def cpu_sets_for_ranks(n: int, sysfs: str = '/sys', allowed: Optional[Sequence[i
             return [cpus for _ in range(k)]
         return [cpus[i * len(cpus) // k:(i + 1) * len(cpus) // k] for i in range(k)]
 
-    nodes: List[int] = []
-    try:
-        cards = sorted(glob.glob(os.path.join(sysfs, 'class/drm/card[0-9]*')),
-                       key=lambda p: int(''.join(ch for ch in os.path.basename(p) if ch.isdigit())))
-        for c in cards:
-            if '-' in os.path.basename(c):                       # connectors (card0-DP-1), not devices
-                continue
-            drv = os.path.join(c, 'device/driver')
-            if os.path.exists(drv) and os.path.basename(os.path.realpath(drv)) != 'amdgpu':
-                continue
-            nodes.append(int(open(os.path.join(c, 'device/numa_node')).read().strip()))
-    except (OSError, ValueError):
-        nodes = []
+    if nodes is not None:
+        nodes = list(nodes)
+    elif any(os.environ.get(v) for v in _VISIBLE_VARS):
+        # HIP device r is not DRM card r under a visible-devices subset: do not guess (gpu_numa_nodes resolves it in the rank)
+        return even_slices(allowed, n)
+    else:
+        nodes = _drm_numa_nodes(sysfs)
     if len(nodes) < n or any(v < 0 for v in nodes[:n]):
         return even_slices(allowed, n)
     nodes = nodes[:n]
@@ -110,20 +126,63 @@ def cpu_sets_for_ranks(n: int, sysfs: str = '/sys', allowed: Optional[Sequence[i
     return out
 
 
-def pin_this_rank(local_rank: int, local_world: int) -> Optional[List[int]]:
-    """host placement of a rank that somebody else started (torchrun): the same CPU set launch_local_ranks would have given
-    it.  No-op when our own launcher pinned it already, when TOPAZ_AMD_NO_AFFINITY=1, or where affinity cannot be set."""
-    if os.environ.get('TOPAZ_AMD_RANK_CPUS') or os.environ.get('TOPAZ_AMD_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
-        return None
+def _drm_numa_nodes(sysfs: str) -> List[int]:
+    """NUMA nodes of the amdgpu devices in DRM card order (only meaningful when every GPU is visible, in that order)"""
+    import glob
+    nodes: List[int] = []
     try:
-        sets = cpu_sets_for_ranks(local_world)
-        if 0 <= local_rank < len(sets) and sets[local_rank]:
-            os.sched_setaffinity(0, set(sets[local_rank]))
-            os.environ['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, sets[local_rank]))
-            return sets[local_rank]
+        cards = sorted(glob.glob(os.path.join(sysfs, 'class/drm/card[0-9]*')),
+                       key=lambda p: int(''.join(ch for ch in os.path.basename(p) if ch.isdigit())))
+        for c in cards:
+            if '-' in os.path.basename(c):                       # connectors (card0-DP-1), not devices
+                continue
+            drv = os.path.join(c, 'device/driver')
+            if os.path.exists(drv) and os.path.basename(os.path.realpath(drv)) != 'amdgpu':
+                continue
+            nodes.append(int(open(os.path.join(c, 'device/numa_node')).read().strip()))
+    except (OSError, ValueError):
+        nodes = []
+    return nodes
+
+
+def _set_affinity_all_threads(cpus: Sequence[int]) -> None:
+    """sched_setaffinity(0, .) moves the calling thread only: threads that exist already (an OpenMP pool, torch's workers)
+    are moved one by one through /proc/self/task"""
+    cpus = set(cpus)
+    os.sched_setaffinity(0, cpus)
+    try:
+        for tid in os.listdir('/proc/self/task'):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except (OSError, ValueError):
+                pass                                    # (a thread that ended meanwhile)
     except OSError:
         pass
-    return None
+
+
+def pin_this_rank(local_rank: int, local_world: int) -> Optional[List[int]]:
+    """Host placement of this rank process, applied by the rank itself (never in a fork hook of the launcher): the CPU set
+    launch_local_ranks handed over in TOPAZ_AMD_RANK_CPUS, else -- torchrun, or a *_VISIBLE_DEVICES subset the launcher would
+    not guess about -- the CPUs next to ITS GPU, resolved through HIP's own PCI address of the device (gpu_numa_nodes), else the
+    DRM card order when every GPU is visible.  Every existing thread is moved.  No-op with TOPAZ_AMD_NO_AFFINITY=1 or where
+    affinity cannot be set; a failure leaves the rank unpinned rather than failing the job."""
+    if os.environ.get('TOPAZ_AMD_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        given = os.environ.get('TOPAZ_AMD_RANK_CPUS')
+        if given:
+            cpus = [int(c) for c in given.split(',') if c.strip()]
+        else:
+            nodes = gpu_numa_nodes(local_world) if any(os.environ.get(v) for v in _VISIBLE_VARS) else None
+            sets = cpu_sets_for_ranks(local_world, nodes=nodes)
+            cpus = sets[local_rank] if 0 <= local_rank < len(sets) else []
+        if not cpus:
+            return None
+        _set_affinity_all_threads(cpus)
+        os.environ['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, cpus))
+        return list(cpus)
+    except (OSError, ValueError):
+        return None
 
 
 def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
@@ -142,13 +201,13 @@ def launch_local_ranks(n: int, argv: Sequence[str], env: Optional[dict] = None, 
     # host placement: rank r on the CPUs next to GPU r (cpu_sets_for_ranks; TOPAZ_AMD_NO_AFFINITY=1 leaves the ranks unpinned)
     cpu_sets = None if base.get('TOPAZ_AMD_NO_AFFINITY') == '1' else cpu_sets_for_ranks(n)
     for r in range(n):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        pin = None
-        if cpu_sets and cpu_sets[r] and hasattr(os, 'sched_setaffinity'):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
+        # the rank pins ITSELF to these CPUs first thing in init_from_env (pin_this_rank): no preexec_fn -- this process has
+        # imported torch and is multi-threaded, where a fork hook may deadlock, and a failure to pin must not fail the launch
+        if cpu_sets and cpu_sets[r] and not any(base.get(v) for v in _VISIBLE_VARS):
             e['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, cpu_sets[r]))
-            pin = (lambda cpus: (lambda: os.sched_setaffinity(0, cpus)))(set(cpu_sets[r]))
         # (stdin is not shared: N readers of one pipe would each see a part of it -- the launcher resolves stdin input itself)
-        procs.append(subprocess.Popen(list(argv), env=e, stdin=subprocess.DEVNULL, preexec_fn=pin))
+        procs.append(subprocess.Popen(list(argv), env=e, stdin=subprocess.DEVNULL))
     t0 = time.time()
     codes: List[Optional[int]] = [None] * n
     try:
@@ -232,44 +291,47 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
     """Gather per-image pick tables to rank `dst`.
 
     Every rank passes the images it owns: ids, scores[i] (fp32 [n_i]) and coords[i] (int32 [n_i, d]).
-    Exchange: one all_gather of (image count, row count) per rank, then one gather of the
-    concatenated (id, n) headers and one of the (x, y[, z], score-bits) rows, padded to the largest
-    rank.  Rows are a few hundred KB per micrograph, so the step is latency-bound; each peer writes to
-    the root over its own xGMI link.  Returns on dst a dict id -> (scores, coords) (CPU tensors), on
-    the other ranks None.
+    Exchange: the table sizes are data (the picks of an image), so one small all_gather of (images, rows, d) per rank fixes the
+    stride -- read back with ONE device-to-host copy -- and then ONE gather moves every rank's table as a single int32 buffer
+    packed on the device: `max_img` (id, n) header pairs followed by `max_rows` rows of (x, y[, z], score bits), padded to the
+    largest rank.  A few hundred KB per micrograph: latency-bound, each peer writes to the root over its own xGMI link.
+    Returns on dst a dict id -> (scores, coords) (CPU tensors), on the other ranks None.
     """
     d = coords[0].shape[1] if len(coords) else 2
     if not (dist.is_available() and dist.is_initialized()):
         return {int(i): (s.cpu(), c.cpu()) for i, s, c in zip(image_ids, scores, coords)}
     world, rank = dist.get_world_size(), dist.get_rank()      # (a 1-rank group takes the collective path too)
     n_img = len(image_ids)
-    n_rows = int(sum(int(s.numel()) for s in scores))
+    counts = [int(s.numel()) for s in scores]                  # (shapes: host-side knowledge, no device read)
+    n_rows = int(sum(counts))
     meta = torch.tensor([n_img, n_rows, d], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    max_img = max(int(m[0]) for m in metas)
-    max_rows = max(int(m[1]) for m in metas)
-    d = max(int(m[2]) for m in metas)
-    head = torch.zeros((max(max_img, 1), 2), dtype=torch.int64, device=device)
-    for k, (i, s) in enumerate(zip(image_ids, scores)):
-        head[k, 0], head[k, 1] = int(i), int(s.numel())
-    rows = torch.zeros((max(max_rows, 1), d + 1), dtype=torch.int32, device=device)
+    metas_t = torch.zeros(world * 3, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(metas_t, meta)
+    metas = metas_t.view(world, 3).cpu().tolist()              # the one host read
+    max_img = max(1, max(m[0] for m in metas))
+    max_rows = max(1, max(m[1] for m in metas))
+    d = max(m[2] for m in metas)
+    w = d + 1
+    # one buffer per rank: [max_img x (id, n)] ++ [max_rows x (coords..., score bits)], int32
+    buf = torch.zeros(2 * max_img + w * max_rows, dtype=torch.int32, device=device)
+    if n_img:
+        head = torch.tensor([[int(i), c] for i, c in zip(image_ids, counts)], dtype=torch.int32)
+        buf[:2 * n_img] = head.reshape(-1).to(device, non_blocking=True)
     if n_rows:
-        cat_c = torch.cat([c.to(device=device, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
-        cat_s = torch.cat([s.to(device=device, dtype=torch.float32).reshape(-1) for s in scores], 0)
-        rows[:n_rows, :d] = cat_c
-        rows[:n_rows, d] = cat_s.view(torch.int32)          # bit-exact transport of the fp32 scores
-    heads = [torch.zeros_like(head) for _ in range(world)] if rank == dst else None
-    rowss = [torch.zeros_like(rows) for _ in range(world)] if rank == dst else None
-    dist.gather(head, heads, dst=dst)
-    dist.gather(rows, rowss, dst=dst)
+        rows = buf[2 * max_img:2 * max_img + w * n_rows].view(n_rows, w)
+        rows[:, :d] = torch.cat([c.to(device=device, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
+        rows[:, d] = torch.cat([s.to(device=device, dtype=torch.float32).reshape(-1) for s in scores], 0).view(torch.int32)
+    bufs = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, bufs, dst=dst)
     if rank != dst:
         return None
     out = {}
+    allb = torch.stack(bufs, 0).cpu()                          # one copy of everything gathered
     for r in range(world):
-        h, rw = heads[r].cpu(), rowss[r].cpu()
+        h = allb[r, :2 * max_img].view(max_img, 2)
+        rw = allb[r, 2 * max_img:].view(max_rows, w)
         off = 0
-        for k in range(int(metas[r][0])):
+        for k in range(metas[r][0]):
             iid, n = int(h[k, 0]), int(h[k, 1])
             blk = rw[off:off + n]
             out[iid] = (blk[:, d].contiguous().view(torch.float32).clone(), blk[:, :d].clone())

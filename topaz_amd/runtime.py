@@ -59,6 +59,26 @@ class Context:
         """patch lanes of tpz_denoise_2d / _3d (two auxiliary streams; an int 2 .. 4: that many); off: every launch on the ctx stream"""
         check(self.lib.tpz_ctx_set_lanes(self.handle, int(on)), self.handle)
 
+    def set_tiling(self, limit_px: int = 40 << 20, tile: int = 4096) -> None:
+        """internal tiling of the scoring pass: images above `limit_px` pixels are scored in tile^2 tiles with a receptive-field halo"""
+        check(self.lib.tpz_ctx_set_tiling(self.handle, int(limit_px), int(tile)), self.handle)
+
+    def set_raster(self, on: bool = True) -> None:
+        """patch raster of the large 8-wave conv launches: each XCD walks 8 x 4 blocks of neighbouring tiles (default on)"""
+        check(self.lib.tpz_ctx_set_raster(self.handle, 1 if on else 0), self.handle)
+
+    def set_range(self, on: bool = True) -> None:
+        """range scaling of the scoring pass: run on x * 2^-s with the biases scaled alike when max|x| > 32 (default on)"""
+        check(self.lib.tpz_ctx_set_range(self.handle, 1 if on else 0), self.handle)
+
+    def set_batch(self, n: int = 8) -> None:
+        """patches / tiles per batched launch of tpz_denoise_2d / _3d on the 2xf16 path (0: off, the patch lanes instead)"""
+        check(self.lib.tpz_ctx_set_batch(self.handle, int(n)), self.handle)
+
+    def launches(self) -> int:
+        """kernel launches issued on this context so far (convolutions and elementwise)"""
+        return int(self.lib.tpz_prof_launches(self.handle))
+
     def set_roi(self, on: bool = True) -> None:
         """patch windows of tpz_denoise_2d: each layer of a patch computes only what the kept centre depends on (default on)"""
         check(self.lib.tpz_ctx_set_roi(self.handle, 1 if on else 0), self.handle)
@@ -338,6 +358,18 @@ class DeviceModel:
         check(lib.tpz_model_load(self.ctx.handle, arr, n, blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(h)),
               self.ctx.handle)
         self.handle = h
+        n_conv, n_split, off = self.split_layers()
+        if 0 < n_split < n_conv:
+            import warnings
+            warnings.warn(f'topaz_amd: {n_conv - n_split} of {n_conv} convolution layers of this model have no 2xf16 kernel and run '
+                          f'on the fp32 matrix-core kernels (correct, several times slower): {off}', RuntimeWarning, stacklevel=3)
+
+    def split_layers(self) -> Tuple[int, int, str]:
+        """(convolution layers, those on the 2xf16 path, description of the others)"""
+        a, b = C.c_int(), C.c_int()
+        buf = C.create_string_buffer(512)
+        check(self.ctx.lib.tpz_model_split_layers(self.handle, C.byref(a), C.byref(b), buf, 512), self.ctx.handle)
+        return a.value, b.value, buf.value.decode()
 
     def __del__(self):
         try:

@@ -15,20 +15,29 @@ from typing import List
 import numpy as np
 
 INIT_PIS = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95, 0.98, 1.0)     # stats.py:91
+_FIT_ARRAYS = ('mus', 'stds', 'pis', 'logps')                                    # per-initialisation results (metadata)
+
+
+def _lattice_points(radius: int, dims: int) -> int:
+    """integer offsets within `radius` of the origin: a disc (dims 2) or a ball (dims 3)"""
+    k = np.arange(-int(radius), int(radius) + 1, dtype=np.int64) ** 2
+    d2 = k[:, None] + k[None, :]
+    if dims == 3:
+        d2 = d2[:, :, None] + k[None, None, :]
+    return int(np.count_nonzero(d2 <= int(radius) ** 2))
 
 
 def pixels_given_radius(radius, dims=2):
-    """number of pixels of a disc / ball of that radius (stats.py:17-26)"""
-    g = np.linspace(-radius, radius, 2 * radius + 1)
-    xx, yy, zz = np.meshgrid(g, g, g)
-    d2 = xx ** 2 + yy ** 2
+    """Pixels the reference attributes to a particle of that radius (stats.py:17-26).  Its mask always lives on a CUBE of side
+    2r + 1 whatever `dims` is; in 2-D the z axis simply does not enter the distance, so the disc is counted once per z plane --
+    2r + 1 times.  `calculate_pi` feeds that number on, so it is kept."""
     if dims == 3:
-        d2 = d2 + zz ** 2
-    return int((d2 <= radius ** 2).astype(int).sum())
+        return _lattice_points(radius, 3)
+    return _lattice_points(radius, 2) * (2 * int(radius) + 1)
 
 
 def calculate_pi(expected_num_particles, radius, total_pixels, dims=2):
-    """stats.py:29-34"""
+    """prior fraction of particle pixels (stats.py:29-34)"""
     return pixels_given_radius(radius, dims=dims) * expected_num_particles / total_pixels
 
 
@@ -45,66 +54,84 @@ def norm_fit(x, alpha=900, beta=1, scale=1, num_iters=100, use_cuda=True, verbos
     return mus[i], stds[i], pis_fit[i], logps[i], mus, stds, pis_fit, logps
 
 
+def _fit_pixels(x: np.ndarray, sample: int):
+    """the pixels the mixture is fitted on and the weight each one carries: all of them, or every `sample`-th of them drawn
+    without replacement from the GLOBAL NumPy RNG -- the reference's contract (stats.py:55-60): a run seeded with
+    np.random.seed fits the same pixels here and there"""
+    if sample <= 1:
+        return x, 1
+    n = int(np.round(x.size / sample))
+    return np.random.choice(x.ravel(), size=n, replace=False), x.size / n
+
+
 def normalize(x, alpha=900, beta=1, num_iters=100, sample=1, method='gmm', use_cuda=True, verbose=False):
-    """stats.py:37-84.  Returns (normalised float32 image, metadata dict)."""
+    """(x - mu) / std as float32 plus the metadata dict of stats.py:37-84; mu, std = the image's own mean and standard
+    deviation (`affine`) or the background component of the fitted two-component mixture (`gmm`)."""
     if method == 'affine':
-        mu, std = float(x.mean()), float(x.std())
-        return ((x - mu) / std).astype(np.float32), {'mu': mu, 'std': std, 'pi': 1}
-    x_sample, scale = x, 1
-    if sample > 1:
-        n = int(np.round(x.size / sample))
-        scale = x.size / n
-        x_sample = np.random.choice(x.ravel(), size=n, replace=False)
-    mu, std, pi, logp, mus, stds, pis, logps = norm_fit(x_sample, alpha=alpha, beta=beta, scale=scale,
-                                                        num_iters=num_iters, verbose=verbose)
-    out = ((x - mu) / std).astype(np.float32)
-    meta = {'mu': mu, 'std': std, 'pi': pi, 'logp': logp, 'mus': mus, 'stds': stds, 'pis': pis, 'logps': logps,
-            'alpha': alpha, 'beta': beta, 'sample': sample}
-    return out, meta
+        meta = {'mu': float(x.mean()), 'std': float(x.std()), 'pi': 1}
+    else:
+        pixels, weight = _fit_pixels(x, sample)
+        fit = norm_fit(pixels, alpha=alpha, beta=beta, scale=weight, num_iters=num_iters, verbose=verbose)
+        meta = dict(zip(('mu', 'std', 'pi', 'logp') + _FIT_ARRAYS, fit))
+        meta.update(alpha=alpha, beta=beta, sample=sample)
+    return ((x - meta['mu']) / meta['std']).astype(np.float32), meta
+
+
+def _jsonable(meta: dict) -> dict:
+    """the metadata with NumPy arrays and scalars as plain lists and floats"""
+    out = {}
+    for k, v in meta.items():
+        if k in _FIT_ARRAYS:
+            out[k] = np.asarray(v).tolist()
+        elif isinstance(v, np.generic):
+            out[k] = v.item()
+        else:
+            out[k] = v
+    return out
 
 
 class Normalize:
-    """per-file worker of `topaz normalize` / `topaz preprocess` (stats.py:277-331)"""
+    """per-file worker of `topaz normalize` / `topaz preprocess` (stats.py:277-331): load, optional Fourier down-sampling,
+    normalisation, one output file per requested format, optional `<name>.metadata.json`."""
 
     def __init__(self, dest, scale, affine, num_iters, alpha, beta, sample, metadata, formats, use_cuda=True):
-        self.dest, self.scale, self.affine, self.num_iters = dest, scale, affine, num_iters
-        self.alpha, self.beta, self.sample, self.metadata, self.formats = alpha, beta, sample, metadata, formats
+        self.dest, self.scale, self.formats, self.metadata = dest, scale, formats, metadata
+        self.fit_args = dict(alpha=alpha, beta=beta, num_iters=num_iters, sample=sample, method='affine' if affine else 'gmm')
+
+    def _load(self, path):
+        """(float32 pixels, MRC header or None, extended header or None), down-sampled by `scale` with the header's size
+        fields following"""
+        from .utils.image import downsample, load_image
+        loaded = load_image(path, make_image=False)
+        pixels, header, extended = loaded if isinstance(loaded, tuple) else (loaded, None, None)
+        pixels = pixels.astype(np.float32)
+        if self.scale > 1:
+            pixels = downsample(pixels, self.scale)
+            if header:
+                header = header._replace(ny=pixels.shape[0], nx=pixels.shape[1])
+        return pixels, header, extended
 
     def __call__(self, path):
-        from .utils.image import downsample, load_image, save_image
-        image = load_image(path, make_image=False)
-        image, header, extended_header = image if type(image) is tuple else (image, None, None)
-        x = image.astype(np.float32)
-        if self.scale > 1:
-            x = downsample(x, self.scale)
-            if header:
-                header = header._replace(ny=x.shape[0], nx=x.shape[1])
-        x, metadata = normalize(x, alpha=self.alpha, beta=self.beta, num_iters=self.num_iters,
-                                method='affine' if self.affine else 'gmm', sample=self.sample)
+        from .utils.image import save_image
+        pixels, header, extended = self._load(path)
+        pixels, meta = normalize(pixels, **self.fit_args)
         name = os.path.splitext(os.path.basename(path))[0]
-        base = os.path.join(self.dest, name)
-        for f in self.formats:
-            save_image(x, base, f=f, header=header, extended_header=extended_header)
+        stem = os.path.join(self.dest, name)
+        for fmt in self.formats:
+            save_image(pixels, stem, f=fmt, header=header, extended_header=extended)
         if self.metadata:
-            md = dict(metadata)
-            for k in ('mus', 'stds', 'pis', 'logps'):
-                if k in md:
-                    md[k] = np.asarray(md[k]).tolist()
-            for k in ('mu', 'std', 'pi', 'logp'):
-                if k in md:
-                    md[k] = float(md[k])
-            with open(base + '.metadata.json', 'w') as fh:
-                json.dump(md, fh, indent=4)
+            with open(stem + '.metadata.json', 'w') as fh:
+                json.dump(_jsonable(meta), fh, indent=4)
         return name
 
 
 def normalize_images(paths: List[str], dest: str, num_workers: int, scale: int, affine: bool, niters: int, alpha: float,
                      beta: float, sample: int, metadata: bool, formats: List[str], use_cuda: bool = True,
                      verbose: bool = False):
-    """stats.py:334-352; the worker pool of the reference is not used: the fit runs on the GPU"""
+    """stats.py:334-352 (`num_workers` is accepted and unused: the fit runs on the GPU, one image at a time)"""
     os.makedirs(dest, exist_ok=True)
-    process = Normalize(dest, scale, affine, niters, alpha, beta, sample, metadata, formats)
+    worker = Normalize(dest, scale, affine, niters, alpha, beta, sample, metadata, formats)
     for path in paths:
-        name = process(path)
+        name = worker(path)
         if verbose:
             print('# processed:', name, file=sys.stderr)
