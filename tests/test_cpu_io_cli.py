@@ -144,3 +144,33 @@ def test_via_csv_region_table():
     out = io.StringIO()
     write_via_csv(out, t.drop(columns='score'))
     assert out.getvalue().splitlines()[1] == 'b.png,-1,{},2,0,"{""name"":""point"",""cx"":44,""cy"":87}",{}'
+
+
+def test_mrc_read_into_decodes_like_parse(tmp_path):
+    """mrc.read_into (the feed's route into pinned memory): every real scalar mode decodes to the float32 values `parse` +
+    astype give, header and extended header alike; the vector modes hand over to `parse`; a truncated file is an error"""
+    import pytest
+    from topaz_amd import mrc
+    rs = np.random.RandomState(0)
+    for dt, mode in ((np.float32, 2), (np.int16, 1), (np.uint16, 6), (np.int8, 0), (np.float16, 12)):
+        a = (rs.randn(37, 53) * 50).astype(dt)
+        hdr = mrc.make_header((1,) + a.shape, (1, 1, 1), (0, 0, 0), exthd_size=12)._replace(mode=mode)
+        p = tmp_path / f'm{mode}.mrc'
+        p.write_bytes(mrc.header_struct.pack(*list(hdr)) + b'extendedhdr!' + a.tobytes())
+        ref, h, e = mrc.parse(p.read_bytes())
+        got, h2, e2 = mrc.read_into(str(p), lambda shape: np.empty(shape, np.float32))
+        assert got.dtype == np.float32 and np.array_equal(got, ref.astype(np.float32)) and h2 == h and e2 == e == b'extendedhdr!'
+    vol = rs.randn(3, 8, 9).astype(np.float32)
+    p = tmp_path / 'vol.mrc'
+    with open(p, 'wb') as f:
+        mrc.write(f, vol)
+    got, h, _ = mrc.read_into(str(p), lambda shape: np.empty(shape, np.float32))
+    assert got.shape == (3, 8, 9) and np.array_equal(got, vol)
+    cplx = mrc.make_header((1, 4, 4), (1, 1, 1), (0, 0, 0))._replace(mode=4)
+    p = tmp_path / 'c.mrc'
+    p.write_bytes(mrc.header_struct.pack(*list(cplx)) + np.zeros(16, np.complex64).tobytes())
+    assert mrc.read_into(str(p), lambda shape: np.empty(shape, np.float32)) is None
+    p = tmp_path / 'short.mrc'
+    p.write_bytes(mrc.header_struct.pack(*list(mrc.make_header((1, 8, 8), (1, 1, 1), (0, 0, 0)))) + b'\0' * 100)
+    with pytest.raises(ValueError):
+        mrc.read_into(str(p), lambda shape: np.empty(shape, np.float32))

@@ -1,5 +1,5 @@
 // Timing ablations of conv_split_kernel (results are NOT numerically meaningful with ABL != 0).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I topaz_amd/csrc tools/split_ablate.hip -o tools/_bin/split_ablate
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I topaz_amd/csrc tools/split_ablate.hip -o tools/_run/split_ablate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -276,6 +276,35 @@ int main(int argc, char** argv) {
         quick<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);
         quick<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
         quick<SplitCfg<3, 1, 48, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT48 4w", 48, 48, 1024);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "r4a") {
+        // round 4: wave tiles with more MFMAs per step for the narrow layers (NW = 8 pixel fragments per wave), the fcnn body
+        quick<SplitCfg<11, 1, 64, 16, 64, 1, 8, 11, 1>, EPI_PLAIN>("K11 D1 MT64 8w 16x64 CC1 (fcnn body)", 64, 64, 2058);
+        quick<SplitCfg<5, 4, 32, 16, 32, 2, 8, 5, 1>, EPI_PLAIN>("K5 D4 MT32 8w 16x32 CC2 (conv127, current)", 32, 32, 2064);
+        quick<SplitCfg<5, 4, 32, 16, 64, 1, 8, 5, 1>, EPI_PLAIN>("K5 D4 MT32 8w 16x64 CC1 NW=8", 32, 32, 2064);
+        quick<SplitCfg<5, 2, 32, 8, 32, 2, 4, 5, 1>, EPI_PLAIN>("K5 D2 MT32 4w 8x32 CC2 (conv127, current)", 32, 32, 2056);
+        quick<SplitCfg<5, 2, 32, 16, 64, 1, 8, 5, 1>, EPI_PLAIN>("K5 D2 MT32 8w 16x64 CC1 NW=8", 32, 32, 2056);
+        quick<SplitCfg<5, 2, 32, 8, 64, 1, 4, 5, 1>, EPI_PLAIN>("K5 D2 MT32 4w 8x64 CC1 NW=8", 32, 32, 2056);
+        quick<SplitCfg<3, 2, 64, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D2 MT64 4w 8x32 (ResNet8 conv0, current)", 64, 64, 2052);
+        quick<SplitCfg<3, 2, 64, 16, 48, 2, 8, 3, 1>, EPI_PLAIN>("K3 D2 MT64 8w 16x48 NW=6", 64, 64, 2052);
+        quick<SplitCfg<3, 2, 64, 16, 48, 2, 8, 3, 2>, EPI_PLAIN>("K3 D2 MT64 8w 16x48 NW=6 S=2", 64, 64, 2052);
+        quick<SplitCfg<3, 2, 32, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D2 MT32 4w 8x32 (resnet8_u32, current)", 32, 32, 2052);
+        quick<SplitCfg<3, 2, 32, 8, 64, 1, 4, 3, 1>, EPI_PLAIN>("K3 D2 MT32 4w 8x64 CC1 NW=8", 32, 32, 2052);
+        quick<SplitCfg<3, 2, 32, 16, 64, 1, 8, 3, 1>, EPI_PLAIN>("K3 D2 MT32 8w 16x64 CC1 NW=8", 32, 32, 2052);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "r4b") {
+        // 64-channel dilated layers: 16x48 tiles on 8 waves (NW = 6) against the current tiles, plain and residual epilogues
+        quick<SplitCfg<3, 2, 64, 8, 32, 2, 4, 3, 1>, EPI_RES>("K3 D2 MT64 4w 8x32 RES (current)", 64, 64, 2052);
+        quick<SplitCfg<3, 2, 64, 16, 48, 2, 8, 3, 1>, EPI_RES>("K3 D2 MT64 8w 16x48 RES", 64, 64, 2052);
+        quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w 16x32 S=2 RES (current)", 64, 64, 2056);
+        quick<SplitCfg<3, 4, 64, 16, 48, 2, 8, 3, 1>, EPI_RES>("K3 D4 MT64 8w 16x48 RES", 64, 64, 2056);
+        quick<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D4 MT64 8w 16x32 S=2 (current)", 64, 64, 2056);
+        quick<SplitCfg<3, 4, 64, 16, 48, 2, 8, 3, 1>, EPI_PLAIN>("K3 D4 MT64 8w 16x48", 64, 64, 2056);
+        quick<SplitCfg<3, 8, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D8 MT64 8w 16x32 S=2 RES (current)", 64, 64, 2064);
+        quick<SplitCfg<3, 1, 64, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT64 4w 8x32 (current)", 64, 64, 2050);
+        quick<SplitCfg<3, 1, 64, 16, 48, 2, 8, 3, 1>, EPI_PLAIN>("K3 D1 MT64 8w 16x48", 64, 64, 2050);
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "unet") {

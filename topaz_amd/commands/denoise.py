@@ -42,7 +42,7 @@ def main(args):
                              args.deconvolve, args.deconv_patch, args.patch_size, args.patch_padding, normalize, use_cuda)
     return denoise_stream(args.micrographs, args.output, args.format_, args.suffix, models, args.lowpass,
                           args.pixel_cutoff, gaus, inv_gaus, args.deconvolve, args.deconv_patch, args.patch_size,
-                          args.patch_padding, normalize, use_cuda)
+                          args.patch_padding, normalize, use_cuda, return_images=False)
 
 
 if __name__ == '__main__':

@@ -1,8 +1,10 @@
 #include "conv_split_registry.h"
-// 64-channel ResidA layers.  d = 1 (also the U-Net dec1.0 parity kernels): 4-wave workgroups, two per CU;
-// d = 2 as well since the epilogue / DMA-issue rewrite; d = 4: 8-wave (its halo does not fit two workgroups' LDS)
+// 64-channel ResidA layers.  d = 1 (also the U-Net dec1.0 parity kernels, which are launched in batches): 4-wave workgroups,
+// two per CU.  d = 2 and d = 4: 16x48 pixels on 8 waves -- 6 pixel fragments per wave instead of 4, so that a K step's fixed
+// cost (DMA issue, barrier, plan) is spread over 72 MFMAs per wave instead of 48: +5 ... 11 % against the 8x32 / 16x32 tiles
+// (tools/split_ablate r4b, profiles/r04_tile_experiments.txt); one step per stage, which is also the form that takes a folded
+// 1x1 projection.
 //                K  D  MT  TH  TW  CC
 TPZ_SPLIT4_RESID(3, 1, 64, 8,  32, 2)
-TPZ_SPLIT4_RESID(3, 2, 64, 8,  32, 2)          // 4 waves, two workgroups per CU: -3 ... -5 % against the 8-wave S=2 tile (split_ablate d2)
-TPZ_SPLIT_RESID_S(3, 4, 64, 16, 32, 2, 2)
-TPZ_SPLIT(3, 4, 64, 16, 32, 2, ::tpz::EPI_PLAIN)        // (one step per stage: takes a folded 1x1 projection)
+TPZ_SPLIT_RESID(3, 2, 64, 16, 48, 2)
+TPZ_SPLIT_RESID(3, 4, 64, 16, 48, 2)

@@ -144,6 +144,28 @@ def denoise_image(mic: np.ndarray, models: List[Denoise], lowpass=1, cutoff=0, g
     return out
 
 
+def denoise_image_device(x: torch.Tensor, models: List[Denoise], patch_size: int = -1, padding: int = 0,
+                         normalize: bool = False) -> torch.Tensor:
+    """denoise_image (denoise.py:382-416) for the plain case -- no pixel cutoff, no Gaussian / inverse filter -- with the
+    micrograph staying on the device: population mean / std (the reference's numpy statistics, here a deterministic fp64
+    reduction on the GPU), (x - mu) / std, the networks' average, then either re-normalisation or std * y + mu.  The CLI path
+    spends no host pass over the 16.7 M pixels this way (the numpy version costs ~130 ms per 4096^2 micrograph, 7x the GPU
+    work of the network)."""
+    from . import runtime as rt
+    mu, std = rt.mean_std(x, unbiased=False)
+    xn = rt.affine(x, 1.0 / std, -mu / std)
+    out = None
+    for model in models:
+        y = model.denoise_device(xn, patch_size, padding)
+        out = y if out is None else out + y
+    if len(models) > 1:
+        out = out / len(models)
+    if normalize:
+        m2, s2 = rt.mean_std(out, unbiased=False)
+        return rt.affine(out, 1.0 / s2, -m2 / s2)
+    return rt.affine(out, std, mu)
+
+
 # ---- file-level drivers -----------------------------------------------------------------------------------------------
 # Counterparts of denoise_stack (denoise.py:419-447), denoise_stream (:450-490), denoise_tomogram (:495-530) and
 # denoise_tomogram_stream (:533-557): same arguments, same files on disk.  Structure here: a Job names one input and its
@@ -214,8 +236,10 @@ def denoise_stack(path: str, output_path: str, models: List[Denoise], lowpass: f
 def denoise_stream(micrographs: List[str], output_path: str, format: str = 'mrc', suffix: str = '',
                    models: List[Denoise] = None, lowpass: float = 1, pixel_cutoff: float = 0, gaus=None, inv_gaus=None,
                    deconvolve: bool = True, deconv_patch: int = 1, patch_size: int = 1024, padding: int = 500,
-                   normalize: bool = True, use_cuda: bool = True):
-    """one output image per micrograph; rank r of a multi-process launch takes micrographs r, r + world, ..."""
+                   normalize: bool = True, use_cuda: bool = True, return_images: bool = True):
+    """one output image per micrograph; rank r of a multi-process launch takes micrographs r, r + world, ...
+    Returns the denoised micrographs like the reference (denoise.py:450-490 keeps every one of them in memory);
+    return_images=False (the CLI, which ignores them) returns the output paths instead."""
     from . import parallel
     from .utils.image import load_image, save_image
     rank, _, world = parallel.init_from_env()
@@ -223,6 +247,11 @@ def denoise_stream(micrographs: List[str], output_path: str, format: str = 'mrc'
         os.makedirs(output_path, exist_ok=True)
     jobs = [_Job(i, micrographs[i], _output_path(micrographs[i], output_path, suffix, '.' + format))
             for i in parallel.shard_indices(len(micrographs), rank, world)]
+
+    plain = (models and lowpass <= 1 and pixel_cutoff <= 0 and gaus is None and inv_gaus is None and not deconvolve and
+             all(m.dims == 2 for m in models))
+    if plain:
+        return _denoise_stream_device(jobs, models, patch_size, padding, normalize, len(micrographs), return_images)
 
     def read(job):
         loaded = load_image(job.src, make_image=False)
@@ -240,6 +269,80 @@ def denoise_stream(micrographs: List[str], output_path: str, format: str = 'mrc'
     out = _run_jobs(jobs, read, process, write, lambda n: print(f'# {n} of {total} completed.', file=sys.stderr, end='\r'))
     print('', file=sys.stderr)
     return out
+
+
+def _denoise_stream_device(jobs: List[_Job], models: List[Denoise], patch_size: int, padding: int, normalize: bool, total: int,
+                           return_images: bool = False) -> list:
+    """the plain `topaz denoise` loop with every pass over the pixels on the device: a reader thread decodes micrograph i+1
+    into pinned memory and queues its upload (extract.ImageFeed), the GPU denoises micrograph i (denoise_image_device), its
+    result is copied into a pinned slot by the copy stream and a writer thread writes micrograph i-1 from there."""
+    import queue
+    import threading
+    from . import runtime as rt
+    from .extract import ImageFeed
+    from .utils.image import save_image
+    results = []
+    if not jobs:
+        return results
+    ctx = models[0].model.device_model.ctx
+    by_src = {}
+    for job in jobs:
+        by_src.setdefault(job.src, []).append(job)
+    out_stage, out_bytes, DEPTH = None, 0, 2
+    free_slots: 'queue.Queue' = queue.Queue()
+    todo: 'queue.Queue' = queue.Queue()
+    failed: list = []
+
+    def writer():
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            stage, k, shape, dst, header, extended, index, _device_result = item      # (the tensor lives until its copy is done)
+            try:
+                stage.wait(k)                                # the D2H of this slot has landed
+                save_image(stage.host_array(k, shape), dst, header=header, extended_header=extended)
+                if return_images:
+                    results[index] = np.array(stage.host_array(k, shape), copy=True)
+            except BaseException as e:                       # surfaces in the main thread
+                failed.append(e)
+            finally:
+                free_slots.put((stage, k))
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    retired = []
+    try:
+        for n, (path, x, header, extended) in enumerate(ImageFeed([j.src for j in jobs], ctx, headers=True)):
+            job = by_src[path].pop(0)
+            y = denoise_image_device(x, models, patch_size, padding, normalize)
+            nbytes = y.numel() * 4
+            if out_stage is None or nbytes > out_bytes:
+                # (a larger image: a new ring; the old one is closed once the writer has drained it)
+                for _ in range(DEPTH if out_stage is not None else 0):
+                    free_slots.get()
+                if out_stage is not None:
+                    retired.append(out_stage)
+                out_bytes = (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
+                out_stage = rt.Stage(ctx, out_bytes, DEPTH)
+                for k in range(DEPTH):
+                    free_slots.put((out_stage, k))
+            stage, k = free_slots.get()
+            if failed:
+                raise failed[0]
+            stage.download(k, y)
+            results.append(job.dst)
+            todo.put((stage, k, tuple(y.shape), job.dst, header, extended, n, y))
+            print(f'# {n + 1} of {total} completed.', file=sys.stderr, end='\r')
+    finally:
+        todo.put(None)
+        th.join()
+        for st in retired + ([out_stage] if out_stage is not None else []):
+            st.close()
+    if failed:
+        raise failed[0]
+    print('', file=sys.stderr)
+    return results
 
 
 def _tomogram_io():

@@ -30,6 +30,7 @@ import numpy as np
 import pandas as pd
 import torch
 
+from . import mrc
 from . import parallel
 from . import runtime as rt
 from .algorithms import match_coordinates, non_maximum_suppression, non_maximum_suppression_3d
@@ -167,8 +168,9 @@ class ImageFeed:
 
     DEPTH = 3
 
-    def __init__(self, paths: Sequence[str], ctx: 'rt.Context'):
-        self.paths, self.ctx = list(paths), ctx
+    def __init__(self, paths: Sequence[str], ctx: 'rt.Context', headers: bool = False):
+        """headers=True: items are (path, tensor, MRC header or None, extended header or None)"""
+        self.paths, self.ctx, self.headers = list(paths), ctx, headers
         self.stage: Optional[rt.Stage] = None
         self.slot_bytes = 0
         self.ready: 'queue.Queue' = queue.Queue(maxsize=self.DEPTH - 1)
@@ -212,27 +214,49 @@ class ImageFeed:
     def _reader(self) -> None:
         try:
             torch.cuda.set_device(self.ctx.device)
-            for path in self.paths:
-                image = np.asarray(load_image(path, make_image=False, return_header=False))
-                nbytes = image.size * 4
+            class _Left(Exception):
+                pass
+
+            held = []
+
+            def pinned(shape):
+                """the pinned buffer of a free staging slot for an image of that shape (the ring grows when it must)"""
+                nbytes = int(np.prod(shape)) * 4
                 if self.stage is None or nbytes > self.slot_bytes:
                     # wait until every slot of the old ring came back, then grow
                     if self.stage is not None:
                         for _ in range(self.DEPTH):
                             if self._get_free() is None:
-                                return
+                                raise _Left()
                     self._ensure_stage(nbytes)
                 slot = self._get_free()
                 if slot is None:
-                    return
-                stage, k = slot
+                    raise _Left()
                 # the slot's previous upload may still be queued (a consumer that only enqueues runs ahead of the copy
                 # stream): the pinned buffer is refilled only after that copy has read it
-                stage.wait(k)
-                host = stage.host_array(k, image.shape)
-                np.copyto(host, image, casting='unsafe')                  # decode/convert straight into pinned memory
+                slot[0].wait(slot[1])
+                held[:] = [slot, nbytes]
+                return slot[0].host_array(slot[1], shape)
+
+            for path in self.paths:
+                header = extended = None
+                try:
+                    # an MRC file is decoded straight into pinned memory (float32: read INTO it); anything else is loaded and
+                    # converted into it
+                    got = mrc.read_into(path, pinned) if os.path.splitext(path)[1] == '.mrc' else None
+                    if got is not None:
+                        host, header, extended = got
+                    else:
+                        loaded = load_image(path, make_image=False)
+                        image, header, extended = loaded if isinstance(loaded, tuple) else (loaded, None, None)
+                        image = np.asarray(image)
+                        host = pinned(image.shape)
+                        np.copyto(host, image, casting='unsafe')
+                except _Left:
+                    return
+                (stage, k), nbytes = held
                 stage.upload(k, nbytes)
-                if not self._put_ready((path, stage, k, image.shape)):
+                if not self._put_ready((path, stage, k, host.shape, header, extended)):
                     return
             self._put_ready(None)
         except BaseException as e:                                            # surface reader failures in the consumer
@@ -252,10 +276,13 @@ class ImageFeed:
                     return
                 if isinstance(item, BaseException):
                     raise item
-                path, stage, k, shape = item
+                path, stage, k, shape, header, extended = item
                 stage.acquire(k)
                 held = (stage, k)
-                yield path, stage.device_tensor(k, shape)
+                if self.headers:
+                    yield path, stage.device_tensor(k, shape), header, extended
+                else:
+                    yield path, stage.device_tensor(k, shape)
         finally:
             if held is not None:
                 held[0].release(held[1])

@@ -60,6 +60,33 @@ def parse(content: bytes) -> Tuple[np.ndarray, Any, Any]:
     return array, header, extended_header
 
 
+def read_into(path: str, alloc):
+    """(image, header, extended header) of an MRC file whose pixels are real scalars (modes 0, 1, 2, 6, 12), decoded as float32
+    straight into the array `alloc(shape)` returns -- a pinned staging buffer: a float32 file is read INTO that memory (one
+    copy from the page cache instead of read + frombuffer + astype + copy), the integer / half modes are converted into it.
+    Returns None for the vector modes (3, 4, 16): the caller takes the general `parse` route."""
+    with open(path, 'rb') as f:
+        header = parse_header(f.read(1024))
+        mode = get_mode_from_header(header)
+        if isinstance(mode, str) or np.dtype(mode).kind == 'c':
+            return None
+        extended_header = f.read(header.next)
+        dt = np.dtype(mode)
+        n = header.nz * header.ny * header.nx
+        shape = (header.ny, header.nx) if header.nz == 1 else (header.nz, header.ny, header.nx)
+        out = alloc(shape)
+        if dt == np.float32:
+            got = f.readinto(memoryview(out.reshape(-1)).cast('B'))
+            if got != 4 * n:
+                raise ValueError(f'{path}: {got} bytes of image data, header says {4 * n}')
+        else:
+            raw = np.frombuffer(f.read(n * dt.itemsize), dtype=dt)
+            if raw.size != n:
+                raise ValueError(f'{path}: {raw.size} pixels, header says {n}')
+            np.copyto(out, raw.reshape(shape), casting='unsafe')
+    return out, header, extended_header
+
+
 def make_header(shape, cella, cellb, mz=1, dtype=np.float32, order=(1, 2, 3), dmin=0, dmax=-1, dmean=-2, rms=-1,
                 exthd_size=0, ispg=0) -> MRCHeader:
     return MRCHeader(shape[2], shape[1], shape[0], get_mode_for_header(dtype), 0, 0, 0, 1, 1, mz,
@@ -69,7 +96,7 @@ def make_header(shape, cella, cellb, mz=1, dtype=np.float32, order=(1, 2, 3), dm
 
 
 def write(f, array, header=None, extended_header=b'', ax=1, ay=1, az=1, alpha=0, beta=0, gamma=0):
-    array = np.asarray(array).astype(np.float32)
+    array = np.ascontiguousarray(array, dtype=np.float32)          # (no copy when it already is)
     if extended_header is None:
         extended_header = b''
     if header is None:
@@ -79,4 +106,4 @@ def write(f, array, header=None, extended_header=b'', ax=1, ay=1, az=1, alpha=0,
         header = header._replace(mode=2)          # only the mode is refreshed (mrc.py:231-232)
     f.write(header_struct.pack(*list(header)))
     f.write(extended_header)
-    f.write(array.tobytes())
+    f.write(memoryview(array.reshape(-1)).cast('B'))               # (the array's own memory: no tobytes() copy)
