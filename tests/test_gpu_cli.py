@@ -152,3 +152,45 @@ def test_extract_tomogram_dims3(gpu_ctx, tmp_path):
     lookup = {tuple(c): s for c, s in zip(ref_c.tolist(), ref_s.tolist())}
     mine = {tuple(r[:3]): r[3] for r in t[['x_coord', 'y_coord', 'z_coord', 'score']].values.tolist()}
     assert max(abs(mine[tuple(map(float, c))] - lookup[c]) for c in common) <= 1e-4
+
+
+def test_single_rank_rccl_first_contact(gpu_ctx):
+    """Everything of the multi-GPU path that one GPU can exercise over the real backend: a 1-rank 'nccl' (= RCCL) process group
+    with a bound device, the size all_gather + the ONE packed gather of pick tables on device tensors, the tomogram reduce, the
+    barrier with device ids, the pre-flight report -- the calls that would otherwise meet RCCL for the first time on the 8-GPU
+    node (run in a child process: a process group cannot be re-created in the test process)."""
+    import subprocess
+    import sys
+    code = '''
+import os, sys, io
+sys.path.insert(0, %r)
+import torch
+from topaz_amd import parallel
+os.environ.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(parallel.free_port()),
+                  TOPAZ_AMD_FORCE_DIST='1')
+rank, local_rank, world = parallel.init_from_env()
+assert (rank, local_rank, world) == (0, 0, 1) and torch.distributed.get_backend() == 'nccl'
+dev = torch.device('cuda', 0)
+buf = io.StringIO()
+info = parallel.preflight(0, 0, 1, stream=buf)
+assert 'device' in info and 'rank=0' in buf.getvalue()
+parallel.barrier(dev)
+assert parallel.sum_over_ranks(1.0, dev) == 1.0 and parallel.max_over_ranks(2.5, dev) == 2.5
+assert parallel.gather_scalars(3.0, dev) == [3.0]
+g = torch.Generator().manual_seed(1)
+scores = [torch.randn(n, generator=g).cuda() for n in (5, 0, 17)]
+coords = [torch.randint(0, 4096, (n, 2), generator=g, dtype=torch.int32).cuda() for n in (5, 0, 17)]
+got = parallel.gather_pick_tables([10, 11, 12], scores, coords, dev)
+assert sorted(got) == [10, 11, 12]
+for i, s, c in zip((10, 11, 12), scores, coords):
+    assert torch.equal(got[i][0], s.cpu()) and torch.equal(got[i][1], c.cpu())
+vol = torch.randn(8, 16, 16, device=dev)
+out = parallel.sum_to_root(vol.clone())
+assert torch.equal(out, vol)
+torch.distributed.destroy_process_group()
+print('rccl-1-ok')
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'rccl-1-ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

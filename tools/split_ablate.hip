@@ -307,6 +307,21 @@ int main(int argc, char** argv) {
         quick<SplitCfg<3, 1, 64, 16, 48, 2, 8, 3, 1>, EPI_PLAIN>("K3 D1 MT64 8w 16x48", 64, 64, 2050);
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "r4c") {
+        // U-Net layers (full resolution / level 2): 8-wave tiles against the 4-wave ones
+        quick<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w 8x32 (current) 96->96 at 1012^2", 96, 96, 1014);
+        quick<SplitCfg<3, 1, 96, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D1 MT96 8w 16x32", 96, 96, 1014);
+        quick<SplitCfg<3, 1, 96, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D1 MT96 8w 16x32 S=2", 96, 96, 1014);
+        quick<SplitCfg<3, 1, 96, 16, 48, 2, 8, 3, 1>, EPI_PLAIN>("K3 D1 MT96 8w 16x48 NW=6", 96, 96, 1014);
+        quick<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w 8x32 S=2 (current) dec1.2 64->32 at 2024^2", 64, 32, 2028);
+        quick<SplitCfg<5, 1, 32, 16, 48, 2, 8, 5, 1>, EPI_PLAIN>("K5 D1 MT32 8w 16x48 NW=6", 64, 32, 2028);
+        quick<SplitCfg<5, 1, 32, 16, 48, 2, 8, 5, 2>, EPI_PLAIN>("K5 D1 MT32 8w 16x48 NW=6 S=2", 64, 32, 2028);
+        quick<SplitCfg<5, 1, 32, 16, 64, 1, 8, 5, 1>, EPI_PLAIN>("K5 D1 MT32 8w 16x64 CC1 NW=8", 64, 32, 2028);
+        quick<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w 8x32 (current) sub-pixel dec1.0 104->256v at 1012^2", 104, 256, 1014);
+        quick<SplitCfg<3, 1, 128, 16, 32, 2, 8, 3, 1>, EPI_PLAIN>("K3 D1 MT128 8w 16x32", 104, 256, 1014);
+        quick<SplitCfg<3, 1, 128, 16, 32, 2, 8, 3, 2>, EPI_PLAIN>("K3 D1 MT128 8w 16x32 S=2", 104, 256, 1014);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "unet") {
         bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
         bench<SplitCfg<3, 1, 128, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT128 4w (sub-pixel dec1.0: 104 -> 256 virtual at 1012^2)", 104, 256, 1014);

@@ -27,11 +27,38 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
+            if world > 1:
+                preflight(rank, local_rank, world)        # one line per rank on stderr; fails fast on a rank without a GPU
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def preflight(rank: int, local_rank: int, world: int, stream=None) -> dict:
+    """First-contact report of a rank of a multi-GPU job, before anything is timed: which device it drives (name, PCI address,
+    NUMA node), the CPUs it is pinned to, the rendezvous it uses -- one line per rank on stderr, so that a hang or a crash in the
+    first collective can be attributed -- and a fail-fast check that the device exists (a rank without a GPU would otherwise
+    die inside RCCL's init with the other ranks waiting on it)."""
+    import sys
+    info = {'rank': rank, 'local_rank': local_rank, 'world': world, 'pid': os.getpid(),
+            'master': f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}",
+            'cpus': os.environ.get('TOPAZ_AMD_RANK_CPUS') or 'unpinned',
+            'visible': {v: os.environ[v] for v in _VISIBLE_VARS if os.environ.get(v)},
+            'ipc_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if local_rank >= n_dev:
+        raise RuntimeError(f'rank {rank}: local rank {local_rank} has no GPU ({n_dev} visible; {info["visible"] or "no *_VISIBLE_DEVICES set"})')
+    pr = torch.cuda.get_device_properties(local_rank)
+    info['device'] = pr.name
+    try:
+        info['pci'] = f'{int(getattr(pr, "pci_domain_id", 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0'
+        info['numa_node'] = int(open(f'/sys/bus/pci/devices/{info["pci"]}/numa_node').read())
+    except (AttributeError, OSError, ValueError):
+        pass
+    print('[topaz_amd rank] ' + ' '.join(f'{k}={v}' for k, v in info.items()), file=stream or sys.stderr, flush=True)
+    return info
 
 
 def under_launcher() -> bool:
