@@ -172,6 +172,7 @@ def test_chained_config4_denoise_score_nms_vs_oracle_chain(gpu_ctx, nets):
     # ... and the chain end to end: the 1e-4 of the first stage passes through the second
     assert e_log <= ATOL
     n_diff, n = _picks_equivalent(s, c, so, co, log_ref, r, 2 * ATOL, thr)
+    print(f'{nets}: {n} picks, {n_diff} differ from the oracle chain (each explained by a competitor within {2 * ATOL:g} of it)')
     assert n_diff <= max(2, n // 100), (n_diff, n)
     # NMS of the oracle's own map on the device is bit-exact
     s2, c2 = non_maximum_suppression(log_ref, r, threshold=thr)

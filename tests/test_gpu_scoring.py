@@ -216,6 +216,10 @@ def test_scoring_3d_vs_reference_golden(gpu_ctx, name):
     # the default path is the plane-stacked 2xf16 one (dilated k^3 convs, 3-D residuals, fused head); the fp32 kernels agree
     eligible, split_runs, fp32_reruns = m.device_model.split_stats()
     assert eligible and split_runs == 1 and fp32_reruns == 0
+    # ... and it is EVERY layer's path: a layer goes to the 2xf16 kernels when pick_split finds one, and for these networks it
+    # finds one for each (include/topaz_hip.h states the rule; this pins which path the 3-D pickers take)
+    n_conv, n_split, off = m.device_model.split_layers()
+    assert n_conv > 0 and n_split == n_conv, off
     gpu_ctx.set_exact(True)
     try:
         y32 = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
