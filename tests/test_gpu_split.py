@@ -226,6 +226,34 @@ def test_raw_count_micrograph_stays_on_the_2xf16_path(gpu_ctx, net):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('hot', [3.0e4, 1.0e6])
+def test_hot_pixels_do_not_starve_the_rest_of_precision(gpu_ctx, hot):
+    """The range exponent follows the BULK of the image (99.9 % quantile), not its maximum: a normalised micrograph with a few
+    hot pixels keeps s = 0, so every logit outside the hot pixels' receptive fields is the one the clean image gives, to the
+    bit or within 1e-4 of the oracle (had the maximum decided, the N(0,1) pixels would have been scaled towards the f16
+    subnormals and lost their lo halves without any flag).  3e4 still fits f16 (2xf16 path, maybe an fp32 re-run when an
+    activation overflows), 1e6 does not (re-run): right either way."""
+    from oracle import scoring as oscoring
+    m, sd = _resnet('resnet8', 64, False)
+    rs = np.random.RandomState(12)
+    x = rs.randn(420, 400).astype(np.float32)
+    xh = x.copy()
+    for (py, px) in ((5, 7), (210, 200), (215, 203), (400, 30)):
+        xh[py, px] = hot
+    ref = oscoring.score('resnet8', sd, xh)
+    y = m(torch.from_numpy(xh).cuda()[None, None])[0, 0].cpu().numpy()
+    assert np.isfinite(y).all()
+    far = np.ones_like(x, dtype=bool)                      # pixels whose 71-pixel receptive field holds no hot pixel
+    for (py, px) in ((5, 7), (210, 200), (215, 203), (400, 30)):
+        far[max(0, py - 36):py + 37, max(0, px - 36):px + 37] = False
+    assert far.sum() > 50000
+    assert float(np.abs(y - ref)[far].max()) <= 1e-4
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(y - ref).max()) <= max(1e-4, 1e-5 * scale)
+    clean = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    assert float(np.abs(y - clean)[far].max()) <= 2e-4
+
+
 @pytest.mark.parametrize('shape', [(256, 320), (253, 190), (150, 140)])
 def test_unet_denoise_on_split_path_matches_oracle(gpu_ctx, shape):
     """The 48-filter U-Net goes down the 2xf16 path: encoder / decoder 3x3 convs, the per-parity decoder kernels

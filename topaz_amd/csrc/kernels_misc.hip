@@ -453,47 +453,53 @@ hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, 
 // the linear head are -- so f(2^-s x; 2^-s b) = 2^-s f(x; b), exactly (powers of two): the pass runs on x * 2^-s with every
 // bias-like vector scaled alike and multiplies its result by 2^s.  s is chosen per image on the device (no host round trip).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
-    unsigned m = 0;              // |x| as bits: monotone for non-negative floats; NaN patterns sort above infinity
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned b = __float_as_uint(x[i]) & 0x7fffffffu;
-        m = b > m ? b : m;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
-        m = t > m ? t : m;
-    }
-    __shared__ unsigned sm[4];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+// histogram of the biased exponents of |x| (integer counts: deterministic whatever the order of the atomics)
+__global__ __launch_bounds__(256) void exp_hist_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) m = sm[w] > m ? sm[w] : m;
-        if (m) atomicMax(out, m);
-    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        atomicAdd(&h[(__float_as_uint(x[i]) >> 23) & 0xffu], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void range_finish_kernel(unsigned* __restrict__ scratch, float target, float* __restrict__ rng,
+// s from the histogram: the exponent e below which all but n / 1024 of the finite pixels lie (the 99.9 % quantile of |x|, to
+// a power of two) is brought to 2^3: s = max(0, e - 127 - 3).  The BULK of the image decides, not its maximum: a hot pixel a
+// thousand times the rest would otherwise push every other pixel towards the f16 subnormals (the lo halves first) without
+// tripping any flag; here it either still fits the f16 range after scaling or trips the overflow flag and the image is
+// re-run on the fp32 kernels -- exact either way.  N(0,1) images: e - 127 = 1, s = 0 (untouched).
+__global__ __launch_bounds__(256) void range_finish_kernel(unsigned* __restrict__ hist, size_t n, float* __restrict__ rng,
                                                            const float* __restrict__ src, float* __restrict__ dst, size_t n_vec) {
-    const unsigned bits = *scratch;
-    int s = 0;
-    if (bits < 0x7f800000u) {                       // finite (an image with inf / NaN is left alone: the overflow flag decides)
-        const float mx = __uint_as_float(bits);
-        while (s < 96 && ldexpf(mx, -s) > target) ++s;
+    __shared__ int s_sh;
+    if (threadIdx.x == 0) {
+        const size_t finite = n - hist[255];
+        const size_t allow = finite >> 10;
+        size_t above = 0;
+        int e = 254;
+        for (; e > 0; --e) {
+            above += hist[e];
+            if (above > allow) break;
+        }
+        int s = e - 127 - 3;
+        s = s < 0 ? 0 : s > 120 ? 120 : s;
+        if (finite == 0) s = 0;
+        s_sh = s;
     }
+    __syncthreads();
+    const int s = s_sh;
     const float down = ldexpf(1.f, -s), up = ldexpf(1.f, s);
     for (size_t i = threadIdx.x; i < n_vec; i += 256) dst[i] = src[i] * down;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        rng[0] = down; rng[1] = 0.f; rng[2] = up; rng[3] = (float)s;
-        *scratch = 0;                               // ready for the next image on this stream
-    }
+    hist[threadIdx.x] = 0;                          // ready for the next image on this stream
+    if (threadIdx.x == 0) { rng[0] = down; rng[1] = 0.f; rng[2] = up; rng[3] = (float)s; }
 }
 
-hipError_t launch_range_fit(const float* x, size_t n, float target, unsigned* scratch, float* rng, const float* src, float* dst,
-                            size_t n_vec, hipStream_t s) {
+hipError_t launch_range_fit(const float* x, size_t n, unsigned* hist, float* rng, const float* src, float* dst, size_t n_vec,
+                            hipStream_t s) {
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
-    if (n) hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, scratch);
-    hipLaunchKernelGGL(range_finish_kernel, dim3(1), dim3(256), 0, s, scratch, target, rng, src, dst, n_vec);
+    if (n) hipLaunchKernelGGL(exp_hist_kernel, dim3(blocks), dim3(256), 0, s, x, n, hist);
+    hipLaunchKernelGGL(range_finish_kernel, dim3(1), dim3(256), 0, s, hist, n, rng, src, dst, n_vec);
     return hipGetLastError();
 }
 

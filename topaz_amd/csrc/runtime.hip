@@ -161,7 +161,7 @@ struct tpz_ctx {
     // scaled copy of its bias arena), the fused head adds no bias (the un-scaling pass does)
     ptrdiff_t bias_shift = 0;
     bool scaled_pass = false;
-    unsigned* d_absmax = nullptr; // scratch word of launch_range_fit
+    unsigned* d_absmax = nullptr; // exponent histogram of launch_range_fit (256 words, kept zeroed)
     bool range_scaling = getenv("TPZ_NO_RANGE") == nullptr;       // tpz_ctx_set_range
     bool raster = getenv("TPZ_NO_RASTER") == nullptr;             // tpz_ctx_set_raster: patch raster of the 8-wave tiles' grids
     // internal tiling of tpz_model_forward (run_image): 2-D images above tile_limit_px pixels are scored in tile_size^2 tiles
@@ -2154,7 +2154,7 @@ int tpz_ctx_create(int device_id, tpz_ctx** out) {
         hipMalloc((void**)&ctx->d_nrm, 4 * NRM_RING * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_counters, NMS_COUNTERS * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc((void**)&ctx->d_flag, 16) != hipSuccess || hipHostMalloc((void**)&ctx->h_flag, 16) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_absmax, 16) != hipSuccess || hipMemset(ctx->d_absmax, 0, 16) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_absmax, 1024) != hipSuccess || hipMemset(ctx->d_absmax, 0, 1024) != hipSuccess ||
         hipMalloc((void**)&ctx->d_zeros, 256) != hipSuccess || hipMemset(ctx->d_zeros, 0, 256) != hipSuccess) {
         delete ctx;
         return fail(nullptr, "tpz_ctx_create: hipMalloc failed");
@@ -2412,7 +2412,8 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
             // RANGE SCALING (scoring networks = programs ending in the linear head): `topaz extract` does not normalise its
             // input (extract.py:234-249), and a raw-count micrograph would leave the f16 range in the stem.  The network is
             // positively homogeneous in (input, biases): it runs on x * 2^-s with its biases scaled alike and the logits are
-            // multiplied back -- exact, powers of two; s = 0 for an image within +-32 (kernels_misc.hip launch_range_fit).
+            // multiplied back -- exact, powers of two; s follows the BULK of the image (its 99.9 % quantile of |x| -> ~8; s = 0 for
+            // a normalised image), so outliers cannot starve the rest of precision (kernels_misc.hip launch_range_fit).
             const bool scaled = ctx->range_scaling && m->layers.back().L.op == TPZ_OP_CONV && m->layers.back().L.head &&
                                 m->d_bias_scaled != nullptr;
             float *xs = nullptr, *rng = nullptr;
@@ -2422,7 +2423,7 @@ int tpz_model_forward(tpz_model* m, const float* d_in, int n, int D, int H, int 
                 xs = (float*)pool_alloc(ctx, n_in * sizeof(float));
                 if (!xs) return fail(ctx, "out of device memory");
                 hipError_t e = enqueue(ctx, [=](hipStream_t st) {
-                    return launch_range_fit(x_b, n_in, 32.f, ctx->d_absmax, rng, m->d_bias_arena, m->d_bias_scaled, m->n_bias_arena, st);
+                    return launch_range_fit(x_b, n_in, ctx->d_absmax, rng, m->d_bias_arena, m->d_bias_scaled, m->n_bias_arena, st);
                 });
                 if (e == hipSuccess) e = enqueue(ctx, [=](hipStream_t st) { return launch_affine_dev(x_b, D, H, W, (long long)H * W, W, rng, xs, st); });
                 if (e != hipSuccess) { pool_release(ctx, xs); return fail(ctx, "range scaling failed: %s", hipGetErrorString(e)); }
