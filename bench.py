@@ -443,9 +443,12 @@ def cli_inclusive(args, dev, n=6):
         n_picks = sum(1 for _ in open(os.path.join(d, 'picks.txt'))) - 1
         # the same networks on a resident micrograph
         x = torch.randn(S, S, device=dev)
+        tl = time.perf_counter()
         dn = Denoise('unet-v0.2.1')
         m = load_model('resnet8_u32')
         m.eval(); m.fill(); m.cuda()
+        torch.cuda.synchronize(dev)
+        load_ms = 1e3 * (time.perf_counter() - tl)          # (what each of the two invocations pays once, whatever the file count)
 
         def step():
             y = dn.denoise_device(x, args.patch_size, args.patch_padding)
@@ -461,7 +464,7 @@ def cli_inclusive(args, dev, n=6):
         return {'value': n / (t2 - t0), 'unit': 'micrographs/s', 'files': n, 'ms_per_micrograph': 1e3 * (t2 - t0) / n,
                 'denoise_ms_per_micrograph': 1e3 * (t1 - t0) / n, 'extract_ms_per_micrograph': 1e3 * (t2 - t1) / n,
                 'first_invocation_ms_per_micrograph': 1e3 * (c2 - c0) / n,
-                'gpu_only_ms_per_micrograph': gpu_ms, 'picks': n_picks,
+                'gpu_only_ms_per_micrograph': gpu_ms, 'model_loading_ms_per_job': load_ms, 'picks': n_picks,
                 'io_mb_per_micrograph': {'read': 2 * mb, 'written': mb},
                 'where': d if base is None else 'tmpfs (/dev/shm)',
                 'note': 'topaz denoise -m unet-v0.2.1 -> topaz extract -m resnet8_u32 through topaz_amd.main in this process, model '
