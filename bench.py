@@ -627,6 +627,22 @@ def main():
         ms, n, fl = sum(k[1] for k in rows), sum(k[2] for k in rows), sum(k[3] for k in rows)
         return {'kernel_ms_per_step': ms, 'launches_per_step': n, 'algorithmic_tflop_per_step': fl / 1e12,
                 'achieved': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+    # what the matrix pipes of THIS box sustain: a register-resident loop of the 2xf16 kernels' MFMA on every SIMD, after the
+    # timed region (profiles/r04_mfma_sustained.txt: with full-entropy operands the board holds ~1.9 GHz, not the 2.4 GHz of the
+    # dense peak; with zero operands the same loop reaches the nominal rate)
+    sustained = None
+    if rank == 0 and is_split:
+        tf_rand, clk_rand = ctx.mfma_sustained(300, False)
+        tf_zero, clk_zero = ctx.mfma_sustained(300, True)
+        sustained = {
+            'f16_dense_tflops': tf_rand, 'fp32_equivalent_tflops': tf_rand / 3.0,
+            'frac_of_sustained': achieved / (tf_rand / 3.0) if tf_rand > 0 else None,
+            'zero_operand_f16_dense_tflops': tf_zero,
+            'shader_clock_vs_zero_operand_run': clk_rand / clk_zero if clk_zero > 0 else None,
+            'what': 'tpz_prof_mfma_sustained: v_mfma_f32_16x16x32_f16 back to back from registers, two waves per SIMD on every CU, '
+                    '0.3 s, operands uniform in [-1, 1] (zero_operand: all zero); no memory traffic.  `frac` above stays against '
+                    'the nominal peak; this is the ceiling the board power management leaves for that instruction',
+        }
     cls_f32, cls_split = klass('conv_mfma'), klass('conv_split')
     cls_f32['frac'] = cls_f32['achieved'] / FP32_MFMA_PEAK_TFLOPS
     cls_split['frac'] = cls_split['achieved'] / SPLIT_PEAK_TFLOPS
@@ -695,9 +711,10 @@ def main():
                 ctx.set_batch(8)
             extras['patch_lanes_unbatched'] = {
                 'value': 2 / t, 'ms_per_step': 1e3 * t / 2, 'steps': 2, 'unit': 'micrographs/s', 'launches_per_step': (l1 - l0) / 2,
-                'note': 'tpz_ctx_set_batch(0): every patch of the denoise stage launches its own layers (two patch lanes); `value` '
-                        'above issues the same layer of 8 patches as one grid -- bit-identical output '
-                        '(tests/test_gpu_denoise.py::test_batched_patches_are_bit_identical)'}
+                'note': 'tpz_ctx_set_batch(0): every patch of the denoise stage launches its own layers, patches alternating on the '
+                        'two patch lanes; `value` above issues the same layer of 8 patches as one grid and alternates the BATCHES '
+                        'on the lanes -- bit-identical output (tests/test_gpu_denoise.py::test_batched_patches_are_bit_identical; '
+                        'same-process A/B of the denoise stage alone: profiles/r04_batch_lanes_ab.txt)'}
             # A/B of the patch windows: the same step with every tensor of every denoise patch computed in full
             ctx.set_roi(False)
             try:
@@ -769,6 +786,7 @@ def main():
                 'traffic_detail': traffic_detail,
                 'peak_basis': ('f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC (2xf16 split)'
                                if is_split else 'fp32 MFMA peak'),
+                'sustained_mfma': sustained,
                 'launches_per_step': dom_n, 'avg_launch_ms': dom_ms / max(1e-9, dom_n),
                 'timed_over': ('the timed steps themselves (HIP events on the launch stream)' if not args.no_kernel_timing
                                else 'one extra step after the timed region'),

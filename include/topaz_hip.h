@@ -291,6 +291,13 @@ int tpz_prof_get_kernel(tpz_ctx* ctx, int rank, double* ms, long long* launches,
 /* algorithmic HBM bytes (inputs with halo + weights read once, outputs written once) of the launches behind
  * tpz_prof_get_kernel(rank): the bandwidth of the kernels that are HBM-bound rather than MFMA-bound */
 int tpz_prof_get_kernel_bytes(tpz_ctx* ctx, int rank, double* bytes);
+/* The matrix-pipe rate this board sustains (diagnostic, no reference counterpart): a register-resident loop of
+ * v_mfma_f32_16x16x32_f16 -- the instruction of the 2xf16 kernels -- on every SIMD for about `ms` milliseconds, operands
+ * uniform in [-1, 1] (zero_operands = 0) or all zero (1).  *tflops = dense f16 TFLOP/s (3 such products make one fp32-equivalent
+ * multiply-add on the 2xf16 path); *clock_ratio = s_memtime / s_memrealtime ticks over the loop (proportional to the shader
+ * clock; may be NULL).  With full-entropy operands the power management holds the clock well below the 2.4 GHz the dense peak
+ * is quoted at: bench.py reports the dominant kernel against both. */
+int tpz_prof_mfma_sustained(tpz_ctx* ctx, int ms, int zero_operands, double* tflops, double* clock_ratio);
 
 #ifdef __cplusplus
 }

@@ -417,3 +417,14 @@ def test_persistent_workgroups_are_bit_identical(gpu_ctx, case, wgs):
     assert not ovf0 and not ovf1
     assert _err(y0, ref) <= 1e-4
     assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+
+
+def test_sustained_mfma_probe_reports_a_plausible_rate(gpu_ctx):
+    """tpz_prof_mfma_sustained (csrc/diag.hip): the register-resident MFMA loop bench.py quotes the dominant kernel against.
+    Zero operands run at (nearly) the nominal dense rate; full-entropy operands are held below it by the power management."""
+    tf_rand, clk_rand = gpu_ctx.mfma_sustained(60, False)
+    tf_zero, clk_zero = gpu_ctx.mfma_sustained(60, True)
+    print(f'sustained v_mfma_f32_16x16x32_f16: {tf_rand:.0f} TFLOP/s on random operands, {tf_zero:.0f} on zeros; '
+          f'clock ratio {clk_rand / clk_zero:.3f}')
+    assert 800 < tf_rand <= tf_zero * 1.02 and 1500 < tf_zero < 2700, (tf_rand, tf_zero)
+    assert clk_rand > 0 and clk_zero > 0

@@ -38,6 +38,9 @@ hipError_t launch_range_fit(const float* x, size_t n, unsigned* hist, float* rng
                             hipStream_t s);
 // y[i] = y[i] * rng[2] + add (skipped on the device when that is the identity)
 hipError_t launch_unscale(float* y, size_t n, const float* rng, float add, hipStream_t s);
+// diag.hip: n_wg 4-wave workgroups each issue 8 * iters v_mfma_f32_16x16x32_f16 per wave on operands read from src (4096 x 16 B);
+// ticks[0] = s_memtime, ticks[1] = s_memrealtime (100 MHz) ticks of wave 0's loop
+hipError_t launch_mfma_spin(const void* src, float* out, int n_wg, int iters, unsigned long long* ticks, hipStream_t s);
 hipError_t launch_extract_tile3d(const float* tomo, int D, int H, int W, int i0, int j0, int k0, int d,
                                  const float* d_g, float* tile, hipStream_t s);
 

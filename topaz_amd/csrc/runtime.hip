@@ -150,7 +150,8 @@ struct tpz_ctx {
     double rec_t0 = 0;                        // (TPZ_TRACE_HOST)
     int rec_cur = 0;
     std::vector<RecOp> rec[tpz::SPLIT_MULTI_MAX];
-    std::vector<Buf> rec_pools[tpz::SPLIT_MULTI_MAX];
+    std::vector<Buf> rec_pools[TPZ_N_LANES][tpz::SPLIT_MULTI_MAX];   // per lane (two batches are in flight at a time) and image
+    int rec_lane = 0;
     long long n_launches = 0;                 // kernel launches issued (tpz_prof_launches)
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
@@ -361,19 +362,23 @@ static hipError_t enqueue(tpz_ctx* ctx, int cls, double flops, const void* key, 
 template <class F>
 static hipError_t enqueue(tpz_ctx* ctx, F&& fn) { return enqueue(ctx, 2, 0.0, nullptr, 0.0, std::forward<F>(fn)); }
 
-static int rec_begin(tpz_ctx* ctx) {
+// `batch_no`: consecutive batches alternate on the patch lanes (lane_enter: the lane's stream and reduction scratch), so that
+// one batch's elementwise launches and small grids run under the other's large ones -- batches of 8 images, two in flight
+static int rec_begin(tpz_ctx* ctx, int batch_no = 0) {
     if (g_trace_host) ctx->rec_t0 = host_now_ms();
     for (auto& r : ctx->rec) r.clear();
+    lane_enter(ctx, batch_no);                  // (no-op without lanes: everything on the ctx stream)
+    ctx->rec_lane = ctx->lanes_on ? batch_no % ctx->lanes_live : 0;
     ctx->rec_on = true;
     ctx->rec_cur = 0;
-    ctx->pool_cur = &ctx->rec_pools[0];
+    ctx->pool_cur = &ctx->rec_pools[ctx->rec_lane][0];
     return 0;
 }
 // image i of the batch: its launches are recorded in its own list, its tensors come from its own pool (the images of a batch
 // run interleaved: nothing of one may alias anything of another)
 static void rec_select(tpz_ctx* ctx, int i) {
     ctx->rec_cur = i;
-    ctx->pool_cur = &ctx->rec_pools[i];
+    ctx->pool_cur = &ctx->rec_pools[ctx->rec_lane][i];
 }
 // leaves a batched pass: whatever is still recorded (an error on the way) is dropped
 static void rec_abort(tpz_ctx* ctx) {
@@ -2170,8 +2175,9 @@ void tpz_ctx_destroy(tpz_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->io_stage) tpz_stage_free(ctx->io_stage);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
-    for (auto& rp : ctx->rec_pools)
-        for (auto& b : rp) (void)hipFree(b.p);
+    for (auto& lane_pools : ctx->rec_pools)
+        for (auto& rp : lane_pools)
+            for (auto& b : rp) (void)hipFree(b.p);
     for (auto& ln : ctx->lanes) {
         for (auto& b : ln.pool) (void)hipFree(b.p);
         if (ln.d_part) (void)hipFree(ln.d_part);
@@ -2623,14 +2629,14 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
     // the patches are independent: on the 2xf16 path they run in batches (the same layer of `batch` patches in one launch:
     // rec_begin / rec_flush), otherwise alternating on the patch lanes
     const bool batched = split && ctx->batch >= 2;
-    if (!batched && lanes_begin(ctx)) return 1;
-    int rc_all = 0, n_patch = 0, slot = 0, slots_left = 0;
+    if (lanes_begin(ctx)) return 1;
+    int rc_all = 0, n_patch = 0, slot = 0, slots_left = 0, n_batches = 0;
     for (int i = 0; i < H && !rc_all; i += patch)
         for (int j = 0; j < W && !rc_all; j += patch) {
             if (batched) {
                 if (slots_left == 0) {
                     if (ctx->rec_on && rec_flush(ctx)) { rc_all = 1; break; }
-                    rec_begin(ctx);
+                    rec_begin(ctx, n_batches++);
                     slots_left = ctx->batch;
                     slot = 0;
                 }
@@ -2668,7 +2674,8 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
     if (batched) {
         if (ctx->rec_on && !rc_all && rec_flush(ctx)) rc_all = 1;
         rec_abort(ctx);
-    } else if (lanes_end(ctx) && !rc_all) rc_all = 1;
+    }
+    if (lanes_end(ctx) && !rc_all) rc_all = 1;
     if (rc_all && !err.empty()) ctx->err = err;
     return rc_all;
 }
@@ -2707,35 +2714,39 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     const size_t tn = (size_t)d * d * d;
     // the tiles are independent: batches of `batch` tiles on the 2xf16 path (as the patches of denoise_2d_pass), else the lanes
     const bool batched = split && ctx->batch >= 2;
-    if (!batched && lanes_begin(ctx)) return 1;
-    enum { MAX_INST = N_LANES > (int)SPLIT_MULTI_MAX ? (int)N_LANES : (int)SPLIT_MULTI_MAX };
-    const int n_lanes = batched ? ctx->batch : ctx->lanes_on ? ctx->lanes_live : 1;
-    float *tiles[MAX_INST] = {}, *touts[MAX_INST] = {};
+    if (lanes_begin(ctx)) return 1;
+    // an instance = one tile in flight: (lane, image of the batch) when batched, a lane otherwise
+    const int lanes_used = ctx->lanes_on ? ctx->lanes_live : 1;
+    const int per_lane = batched ? ctx->batch : 1;
+    const int n_inst = lanes_used * per_lane;
+    float *tiles[N_LANES * SPLIT_MULTI_MAX] = {}, *touts[N_LANES * SPLIT_MULTI_MAX] = {};
     int rc = 0;
-    auto inst_enter = [&](int l) {
-        if (batched) { ctx->rec_cur = l; ctx->pool_cur = &ctx->rec_pools[l]; }
-        else lane_enter(ctx, l);
+    auto inst_enter = [&](int inst) {
+        if (batched) {
+            ctx->rec_cur = inst % per_lane;
+            ctx->pool_cur = &ctx->rec_pools[inst / per_lane][inst % per_lane];
+        } else lane_enter(ctx, inst);
     };
-    for (int l = 0; l < n_lanes; ++l) {
+    for (int l = 0; l < n_inst; ++l) {
         inst_enter(l);
         tiles[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
         touts[l] = (float*)pool_alloc(ctx, tn * sizeof(float));
         if (!tiles[l] || !touts[l]) rc = fail(ctx, "out of device memory");
     }
-    int n_tile = 0, tile_index = 0, slot = 0, slots_left = 0;
+    int n_tile = 0, tile_index = 0, slot = 0, slots_left = 0, n_batches = 0;
     for (int i = 0; i < D && !rc; i += patch)
         for (int j = 0; j < H && !rc; j += patch)
             for (int k = 0; k < W && !rc; k += patch) {
                 if (tile_index++ % n_shards != shard) continue;        // another rank's tile
-                int l = n_tile++ % n_lanes;
+                int l = n_tile++ % n_inst;
                 if (batched) {
                     if (slots_left == 0) {
                         if (ctx->rec_on && rec_flush(ctx)) { rc = 1; break; }
-                        rec_begin(ctx);
+                        rec_begin(ctx, n_batches++);
                         slots_left = ctx->batch;
                         slot = 0;
                     }
-                    l = slot++;
+                    l = ctx->rec_lane * per_lane + slot++;
                     --slots_left;
                 }
                 inst_enter(l);
@@ -2760,13 +2771,13 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
             }
     const std::string err = ctx->err;
     if (batched && ctx->rec_on && !rc && rec_flush(ctx)) rc = 1;
-    for (int l = 0; l < n_lanes; ++l) {
+    for (int l = 0; l < n_inst; ++l) {
         inst_enter(l);
         if (tiles[l]) pool_release(ctx, tiles[l]);
         if (touts[l]) pool_release(ctx, touts[l]);
     }
     if (batched) rec_abort(ctx);
-    else if (lanes_end(ctx) && !rc) rc = 1;
+    if (lanes_end(ctx) && !rc) rc = 1;
     if (rc && !err.empty()) ctx->err = err;
     return rc;
 }
@@ -3327,6 +3338,58 @@ int tpz_prof_get_kernel_bytes(tpz_ctx* ctx, int rank, double* bytes) {
                      });
     *bytes = rank < (int)order.size() ? order[rank].second.bytes : 0.0;
     return 0;
+}
+int tpz_prof_mfma_sustained(tpz_ctx* ctx, int ms, int zero_operands, double* tflops, double* clock_ratio) {
+    if (!ctx || ms < 1 || ms > 5000 || !tflops) return fail(ctx, "tpz_prof_mfma_sustained: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int n_wg = 2 * prop.multiProcessorCount;           // two 4-wave workgroups per CU: two waves per SIMD
+    const size_t n_src = 4096 * 8;
+    std::vector<_Float16> h(n_src);
+    unsigned lcg = 12345u;
+    for (auto& v : h) {
+        lcg = lcg * 1664525u + 1013904223u;
+        v = zero_operands ? (_Float16)0.f : (_Float16)(((int)(lcg >> 8) % 2001 - 1000) * 1e-3f);
+    }
+    void* d_src = nullptr; float* d_out = nullptr; unsigned long long* d_ticks = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    auto run = [&](int iters, float* t_ms) {
+        hipError_t e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) e = launch_mfma_spin(d_src, d_out, n_wg, iters, d_ticks, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(t_ms, e0, e1);
+        return e;
+    };
+    hipError_t e = hipMalloc(&d_src, n_src * sizeof(_Float16));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n_wg * 256 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ticks, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_src, h.data(), n_src * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float t = 0.f;
+    const int probe = 20000;
+    if (e == hipSuccess) e = run(probe, &t);                 // sizes the loop (and is the first of the warm-up)
+    if (e == hipSuccess) {
+        const int iters = (int)std::min(2.0e9, std::max(1000.0, probe * (double)ms / std::max(t, 1e-3f)));
+        e = run(iters, &t);                                  // the power management settles within this one
+        if (e == hipSuccess) e = run(iters, &t);
+        unsigned long long ticks[2] = {};
+        if (e == hipSuccess) e = hipMemcpy(ticks, d_ticks, sizeof(ticks), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            const double flop = 8.0 * 16 * 16 * 32 * 2 * (double)iters * n_wg * 4;
+            *tflops = flop / (t * 1e-3) * 1e-12;
+            // s_memtime over s_memrealtime: proportional to the shader clock (both are read inside the loop's bracket)
+            if (clock_ratio) *clock_ratio = ticks[1] ? (double)ticks[0] / (double)ticks[1] : 0.0;
+        }
+    }
+    if (e != hipSuccess) rc = fail(ctx, "tpz_prof_mfma_sustained: %s", hipGetErrorString(e));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_src); (void)hipFree(d_out); (void)hipFree(d_ticks);
+    return rc;
 }
 int tpz_prof_get_dominant(tpz_ctx* ctx, double* ms, long long* launches, double* flops, char* name, int name_len) {
     return tpz_prof_get_kernel(ctx, 0, ms, launches, flops, name, name_len);

@@ -127,6 +127,14 @@ def _prof_kernels_bytes(self):
     return out
 
 
+def _mfma_sustained(self, ms: int = 300, zero_operands: bool = False):
+    """(dense f16 TFLOP/s, s_memtime / s_memrealtime tick ratio) of a register-resident v_mfma_f32_16x16x32_f16 loop on every SIMD"""
+    tf, ratio = C.c_double(), C.c_double()
+    check(self.lib.tpz_prof_mfma_sustained(self.handle, int(ms), int(bool(zero_operands)), C.byref(tf), C.byref(ratio)), self.handle)
+    return tf.value, ratio.value
+
+
+Context.mfma_sustained = _mfma_sustained
 Context.prof_get_dominant = _prof_get_dominant
 Context.prof_kernels = _prof_kernels
 Context.prof_kernels_bytes = _prof_kernels_bytes
