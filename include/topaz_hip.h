@@ -233,9 +233,11 @@ int tpz_ctx_set_range(tpz_ctx* ctx, int on);
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
 /* Batched patches (2xf16 path): tpz_denoise_2d / _3d record the launches of up to n (<= 8) independent patches / tiles and issue
  * them layer by layer, the same layer of all n as ONE grid (conv_split_multi_kernel): the deep levels of a U-Net are 16-tile
- * launches on a 256-CU chip, ~400 of them per micrograph (denoise.py:299-323 runs the patches one after another).  Default n = 8
- * (TPZ_BATCH=n, TPZ_NO_BATCH=1 in the environment); n = 0: off -- the patches then alternate on the patch lanes above, as do the
- * fp32 kernels (exact mode, overflow re-run) always.  Results are bit-identical either way.
+ * launches on a 256-CU chip, ~400 of them per micrograph (denoise.py:299-323 runs the patches one after another).  Consecutive
+ * batches alternate on the patch lanes above (a batch's elementwise launches and small grids run under the other batch's large
+ * ones: profiles/r04_batch_lanes_ab.txt).  Default n = 8 (TPZ_BATCH=n, TPZ_NO_BATCH=1 in the environment); n = 0: off -- single
+ * patches then alternate on the lanes, as do the fp32 kernels (exact mode, overflow re-run) always.  Results are bit-identical
+ * either way.
  * tpz_prof_launches: kernel launches the library has issued on this context (convolutions, elementwise, NMS sweeps excluded). */
 int tpz_ctx_set_batch(tpz_ctx* ctx, int n);
 long long tpz_prof_launches(tpz_ctx* ctx);
