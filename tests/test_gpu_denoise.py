@@ -281,11 +281,58 @@ def test_tomogram_tiles_sharded_like_ranks_would(gpu_ctx):
         dm.denoise_3d(tomo, -1, 0, shard=0, n_shards=2)
 
 
+@pytest.mark.parametrize('case', ['golden_nf8', 'nf48_ragged', 'nf48_odd_levels', 'nf48_96_48'])
+def test_tile_windows_3d_are_bit_identical(gpu_ctx, case):
+    """Denoise3D keeps the centre patch^3 of every (patch + 2*padding)^3 tile (denoise.py:340-377; 1/8 of the tile at the CLI's
+    96 / 48): on the 2xf16 path every layer computes only the box the kept voxels depend on (need_regions with boxes, the
+    plane-stacked launches' wz0 / Dout).  Identical bits to computing every tensor in full; tiles clipped at the volume's
+    border, odd extents; no overflow re-run caused by voxels nobody computed; and the windows do save work (launch FLOP
+    accounted by the library).  nf48_odd_levels: 80^3 tiles pool to 5^3 and 2^3, the decoder at that level is not an exact 2x
+    upsampling and the layer has no windowed kernel of its own -- the program must then be left whole, not half-windowed."""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    if case == 'golden_nf8':
+        z = load_golden('denoise3d_unet3d_nf8')
+        d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+        vol, patch, pad = z['tomo'], 32, 16
+    else:
+        d = Denoise3D(DenoiseNet('unet-3d', oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
+        if case == 'nf48_ragged':
+            vol, patch, pad = (np.random.RandomState(31).randn(50, 77, 90) * 2 + 1).astype(np.float32), 32, 16
+        elif case == 'nf48_odd_levels':
+            vol, patch, pad = (np.random.RandomState(33).randn(45, 50, 85) * 2 + 1).astype(np.float32), 40, 20
+        else:
+            vol, patch, pad = np.random.RandomState(32).randn(100, 200, 120).astype(np.float32), 96, 48
+    dm = d.model.device_model
+    t = torch.from_numpy(vol).cuda()
+    try:
+        gpu_ctx.set_roi(False)
+        gpu_ctx.prof_enable(1); gpu_ctx.prof_reset()
+        full = dm.denoise_3d(t, patch, pad).cpu().numpy()
+        fl_full = gpu_ctx.prof_get(0)[2]
+        gpu_ctx.set_roi(True)
+        gpu_ctx.prof_reset()
+        win = dm.denoise_3d(t, patch, pad).cpu().numpy()
+        fl_win = gpu_ctx.prof_get(0)[2]
+    finally:
+        gpu_ctx.set_roi(True)
+        gpu_ctx.prof_enable(False)
+    assert np.isfinite(full).all()
+    assert np.array_equal(full, win)
+    assert dm.split_stats()[2] == 0
+    print(f'{case}: {fl_full / 1e12:.2f} TFLOP in full, {fl_win / 1e12:.2f} with windows')
+    if case == 'nf48_odd_levels':
+        assert fl_win == fl_full
+    else:
+        assert fl_win < (0.4 if case == 'nf48_96_48' else 0.8) * fl_full
+
+
 @pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'ragged', 'unet3d'])
 def test_batched_patches_are_bit_identical(gpu_ctx, case):
     """the same layer of up to 8 patches / tiles in ONE launch (conv_split_multi_kernel, runtime.hip rec_flush) against one
     patch at a time: identical bits -- patches of different sizes (corner / edge / interior), patch counts that do not fill
-    the last batch, batch sizes 2, 3 and 8, windows on; the 3-D tiles through the plane-stacked modes"""
+    the last batch, batch sizes 2, 3 and 8, windows on, the batches alternating on the two patch lanes (the default) and
+    all on the ctx stream; the 3-D tiles through the plane-stacked modes"""
     from topaz_amd.denoise import Denoise, Denoise3D
     from topaz_amd.denoising.models import DenoiseNet
     if case == 'unet3d':
@@ -323,8 +370,11 @@ def test_batched_patches_are_bit_identical(gpu_ctx, case):
             outs[b] = run()
             if b == 8:
                 n_batched = gpu_ctx.launches() - n0
+        gpu_ctx.set_lanes(False)
+        outs['8, lanes off'] = run()
     finally:
         gpu_ctx.set_batch(8)
+        gpu_ctx.set_lanes(True)
     assert np.isfinite(one).all()
     for b, y in outs.items():
         assert np.array_equal(one, y), (case, b)

@@ -100,6 +100,9 @@ struct SplitArgs {
     // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
     // centre, so every layer computes only the part of its tensor that the kept pixels depend on (runtime.hip, need_regions).
     int wy0, wx0, wy1, wx1;
+    // ... and, plane-stacked 3-D, the planes [wz0, wz0 + Dout) of the launch lattice (a tile of a tiled tomogram keeps its centre
+    // in z as well).  Dlat: the lattice's full depth (host side only: the share of the layer's FLOP a windowed launch executes)
+    int wz0, Dlat;
     // FOLDED 1x1 projection (ResidA: y = conv1(t) + proj(h), resnet.py:185-202): the last fold_cells cells of the K loop come
     // from `in2` = h with ONE tap each -- the centre tap of the tile layout, read at (row + in2_oy, column + in2_ox) of an
     // in2_H x in2_W tensor -- instead of a separate 1x1 pass that writes a 128-channel residual tensor and reads it back
@@ -442,6 +445,7 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
             pad_y = (a.phase_k / 2 - ooy + 1) / 2;
             pad_z = (a.phase_k / 2 - ooz + 1) / 2;
         }
+        oz += a.wz0;                                         // (the launch covers the planes of its window only)
         ybase = y0 - pad_y; xbase = x0 - pad_x;
     };
     auto set_tile_linear = [&](unsigned L) {

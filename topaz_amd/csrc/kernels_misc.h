@@ -24,7 +24,7 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
                                hipStream_t s, size_t r0 = 0, size_t r1 = (size_t)-1, int x0 = 0, int x1 = 0x7fffffff);
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
                            int norm_out, hipStream_t s, size_t y0 = 0, size_t y1 = (size_t)-1, int x0 = 0, int x1 = 0x7fffffff,
-                           const float* res = nullptr);
+                           const float* res = nullptr, int Hp = 0, int z0 = 0, int z1 = 1);   // Hp > 0: planes [z0, z1) of Hp rows
 hipError_t launch_s2d_split(const float* in, void* out, int d, int h, int w, int H, int W, int dims, unsigned* flag,
                             hipStream_t s);
 hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsigned* flag, hipStream_t s);

@@ -698,18 +698,20 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
     if (big && flag) atomicOr(flag, 1u);      // pixel values beyond the f16 range: the caller re-runs in fp32
 }
 
-// (only rows [y0, y1) x columns [x0, x1) of the 2-D output are produced: the window of the layer, runtime.hip)
+// (only rows [y0, y1) x columns [x0, x1) of the planes [z0, z1) of Hp rows each are produced: the window of the layer,
+// runtime.hip; a 2-D tensor is one plane of `rows` rows)
 __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
                                                        size_t rows, int W, int Wp, float bias,
                                                        const float* __restrict__ nrm, int norm_out, size_t y0, size_t y1,
-                                                       int x0, int x1, const float* __restrict__ res) {
+                                                       int x0, int x1, const float* __restrict__ res, size_t Hp, int z0, int z1) {
     const int nx = x1 - x0;
-    const size_t n = (y1 - y0) * nx;
+    const size_t ny = y1 - y0, n = (size_t)(z1 - z0) * ny * nx;
     float sc = 1.f, sh = 0.f;
     if (nrm && norm_out) { sc = nrm[2]; sh = nrm[3]; }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = x0 + (int)(i % nx);
-        const size_t row = y0 + i / nx;
+        const size_t t = i / nx;
+        const size_t row = (z0 + t / ny) * Hp + y0 + t % ny;
         float acc = 0.f;
         for (int v = 0; v < K; ++v) acc += Y[((size_t)v * rows + row) * Wp + x + v];
         if (res) acc += res[row * W + x];          // (same-size residual: UDenoiseNet3's x - dec1(h), weights negated)
@@ -729,13 +731,16 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
     return hipGetLastError();
 }
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
-                           int norm_out, hipStream_t s, size_t y0, size_t y1, int x0, int x1, const float* res) {
-    if (y1 > rows) y1 = rows;
+                           int norm_out, hipStream_t s, size_t y0, size_t y1, int x0, int x1, const float* res, int Hp, int z0,
+                           int z1) {
+    size_t hp = rows;
+    if (Hp > 0) hp = (size_t)Hp; else { z0 = 0; z1 = 1; }
+    if (y1 > hp) y1 = hp;
     if (x1 > W) x1 = W;
-    const size_t n = (y1 - y0) * (size_t)(x1 - x0);
+    const size_t n = (size_t)(z1 - z0) * (y1 - y0) * (size_t)(x1 - x0);
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out,
-                       y0, y1, x0, x1, res);
+                       y0, y1, x0, x1, res, hp, z0, z1);
     return hipGetLastError();
 }
 

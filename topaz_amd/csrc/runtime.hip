@@ -540,14 +540,16 @@ struct tpz_model {
     long long n_split = 0, n_fallback = 0;
 };
 
-// a rectangle of a 2-D tensor; on = false: the whole tensor
+// a rectangle of a 2-D tensor (planes [z0, z1) of a 3-D one: a box); on = false: the whole tensor
 struct Rect {
     int y0 = 0, x0 = 0, y1 = 0, x1 = 0;
     bool on = false;
+    int z0 = 0, z1 = 1;
     void unite(const Rect& r) {
         if (!r.on) return;
         if (!on) { *this = r; return; }
         y0 = std::min(y0, r.y0); x0 = std::min(x0, r.x0); y1 = std::max(y1, r.y1); x1 = std::max(x1, r.x1);
+        z0 = std::min(z0, r.z0); z1 = std::max(z1, r.z1);
     }
     long long area() const { return (long long)(y1 - y0) * (x1 - x0); }
 };
@@ -1335,6 +1337,11 @@ static void set_window(SplitArgs& a, const Rect& need, int scale = 1, int grow_x
     a.wx1 = std::min(a.Wout, (need.x1 + scale - 1) / scale + grow_x);
     a.wy1 = std::max(a.wy1, a.wy0 + 1); a.wx1 = std::max(a.wx1, a.wx0 + 1);
     a.wy1 = -a.wy1;            // (marks the window as set: launch_split flips it back)
+    if (a.Dout > 1) {          // plane-stacked 3-D: the planes of the box
+        a.Dlat = a.Dout;
+        a.wz0 = std::min(a.Dout - 1, need.z0 / scale);
+        a.Dout = std::max(a.wz0 + 1, std::min(a.Dout, (need.z1 + scale - 1) / scale)) - a.wz0;
+    }
 }
 
 
@@ -1431,6 +1438,7 @@ static int launch_split(tpz_ctx* ctx, const SplitKernelInfo& ks, SplitArgs& a, i
     if (a.wy1 < 0) {
         a.wy1 = -a.wy1;
         flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
+        if (a.Dlat > 0) flops *= (double)a.Dout / a.Dlat;
     } else {
         a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout;
     }
@@ -1753,7 +1761,7 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
     int rc = launch_split(ctx, ks, a, rt.s_n_cog, fl);
     if (!rc) {
         // (labelled: an HBM-bound kernel whose bandwidth bench.py reports -- reads k planes of Wp columns, writes one of W)
-        const double ss_rows = w.on ? (double)(w.y1 - w.y0) : (double)rows, ss_cols = w.on ? (double)(w.x1 - w.x0) : (double)dst.W;
+        const double ss_rows = w.on ? (double)(w.y1 - w.y0) * (L.dims == 3 ? w.z1 - w.z0 : 1) : (double)rows, ss_cols = w.on ? (double)(w.x1 - w.x0) : (double)dst.W;
         // (a residual of the output's own size -- UDenoiseNet3: x - dec1(h), weights negated -- is added here, in fp32)
         const float* resp = sres ? sres->p : nullptr;
         float* dp_ = dst.p;
@@ -1761,9 +1769,10 @@ static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
         const float b0 = L.b_off >= 0 ? rt.bias0 : 0.f;
         const size_t r0 = w.on ? (size_t)w.y0 : 0, r1 = w.on ? (size_t)w.y1 : (size_t)-1;
         const int c0 = w.on ? w.x0 : 0, c1 = w.on ? w.x1 : 0x7fffffff;
+        const int Hp = (w.on && L.dims == 3) ? dst.H : 0, z0 = w.z0, z1 = std::min(dst.D, w.z1);
         hipError_t e = enqueue(ctx, 2, 0.0, "shiftsum (last conv: sum of the k column-kernel planes + bias + un-normalisation)",
                                4.0 * ss_rows * ((double)L.k * (ss_cols + 2 * L.pad) + ss_cols), [=](hipStream_t st) {
-                                   return launch_shiftsum(Y, dp_, k, rows, Wd, Wp, b0, d_nrm, norm_out, st, r0, r1, c0, c1, resp);
+                                   return launch_shiftsum(Y, dp_, k, rows, Wd, Wp, b0, d_nrm, norm_out, st, r0, r1, c0, c1, resp, Hp, z0, z1);
                                });
         if (e != hipSuccess) rc = fail(ctx, "shiftsum failed: %s", hipGetErrorString(e));
     }
@@ -1873,39 +1882,62 @@ static int nearest_src_host(int dst, int in_sz, int out_sz) {
 // launches cover just that (SplitArgs::wy0..wx1).  Nothing else changes: the tensors keep their full-size layout and
 // coordinates, every kept pixel is computed by the same instructions on the same operands as before (bit-identical output,
 // tests/test_gpu_denoise.py), the statistics of the normalisation are still those of the whole padded patch.
-// Returns an empty vector when the program cannot be windowed (3-D, a 2xf16 program with a layer left on an fp32 kernel, an op
-// it does not know).
-static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const Rect& keep, bool split) {
+// 3-D programs (the tiles of Denoise3D.denoise, denoise.py:340-377: patch_size^3 voxels kept of a (patch_size + 2*padding)^3
+// tile -- 1/8 of the tile at the CLI's 96 / 48) are windowed the same way with boxes instead of rectangles, on the 2xf16
+// kernels only: the plane-stacked launches take the planes of the box (SplitArgs::wz0, Dout) besides its rectangle.
+// Returns an empty vector when the program cannot be windowed (a 3-D program on the fp32 kernels, a 2xf16 program with a layer
+// left on an fp32 kernel, an op it does not know).
+static std::vector<Rect> need_regions(const tpz_model* m, int D0, int H0, int W0, const Rect& keep, bool split) {
     const int nl = (int)m->layers.size();
     std::vector<Rect> need;
+    // (TPZ_TRACE_HOST=1 says which check left a program whole)
+    auto bail = [&](int why) {
+        if (g_trace_host) fprintf(stderr, "[tpz host] need_regions: program left whole (check %d)\n", why);
+        need.clear();
+        return need;
+    };
     if (!keep.on || !m->ctx->roi_enabled || nl == 0) return need;
+    const int dims = D0 > 1 ? 3 : 2;
+    if (dims == 3 && !split) return bail(1);
     // shapes of all slots
-    std::vector<int> Hs(m->n_slots, 0), Ws(m->n_slots, 0);
-    Hs[0] = H0; Ws[0] = W0;
+    std::vector<int> Ds(m->n_slots, 1), Hs(m->n_slots, 0), Ws(m->n_slots, 0);
+    Ds[0] = D0; Hs[0] = H0; Ws[0] = W0;
     for (int i = 0; i < nl; ++i) {
         const LayerRT& rt = m->layers[i];
         const tpz_layer& L = rt.L;
-        if (L.dims != 2 || (split && rt.folded_into >= 0)) return need;
+        if (L.dims != dims || (split && rt.folded_into >= 0)) return bail(2);
         if (L.op == TPZ_OP_CONV) {
             // (a 2xf16 program with a layer left on an fp32 kernel stays whole: the format conversions between the two read
             // whole tensors, and what a windowed producer did not write may hold any bit pattern -- the overflow flag)
-            const bool windowed = rt.ks || rt.ks_last || (rt.ks_stem && L.src == 0) || (rt.sphase.valid && !rt.sphase.ki_skip_stem);
-            if (split && !windowed) return need;
             const int g = L.src2 >= 0 ? L.src2 : L.src, span = L.dil * (L.k - 1);
+            // (the per-parity form runs when the skip source is exactly twice the upsampled one -- run_program's rule; with a
+            // 1-channel skip source it either takes that source as a space-to-depth cell or runs it through the fp32 stem kernel
+            // over the whole grid, which reads only the image)
+            const bool parity = rt.sphase.valid && L.src2 >= 0 && Hs[g] == 2 * Hs[L.src] && Ws[g] == 2 * Ws[L.src] &&
+                                (dims == 2 || Ds[g] == 2 * Ds[L.src]);
+            const bool own = rt.ks || rt.ks_last || (rt.ks_stem && L.src == 0);
+            const bool windowed = dims == 3 ? (own || parity) : (own || (rt.sphase.valid && !rt.sphase.ki_skip_stem));
+            if (split && !windowed) return bail(3);
             Hs[L.dst] = Hs[g] + 2 * L.pad - span; Ws[L.dst] = Ws[g] + 2 * L.pad - span;
+            if (dims == 3) Ds[L.dst] = Ds[g] + 2 * L.pad - span;
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             Hs[L.dst] = Hs[L.src] / 2; Ws[L.dst] = Ws[L.src] / 2;
+            if (dims == 3) Ds[L.dst] = Ds[L.src] / 2;
         } else if (L.op == TPZ_OP_MAXPOOL) {
             Hs[L.dst] = Hs[L.src] - L.dil * (L.k - 1); Ws[L.dst] = Ws[L.src] - L.dil * (L.k - 1);
+            if (dims == 3) Ds[L.dst] = Ds[L.src] - L.dil * (L.k - 1);
         } else {
-            return need;
+            return bail(4);
         }
-        if (Hs[L.dst] < 1 || Ws[L.dst] < 1) return need;
+        if (Ds[L.dst] < 1 || Hs[L.dst] < 1 || Ws[L.dst] < 1) return bail(5);
     }
     need.assign(m->n_slots, Rect());
+    // (2-D: every box is the one plane [0, 1))
     auto clip = [&](Rect r, int slot) {
         r.y0 = std::max(0, r.y0); r.x0 = std::max(0, r.x0);
         r.y1 = std::min(Hs[slot], r.y1); r.x1 = std::min(Ws[slot], r.x1);
+        if (dims == 3) { r.z0 = std::max(0, r.z0); r.z1 = std::min(Ds[slot], r.z1); }
+        else { r.z0 = 0; r.z1 = 1; }
         r.on = true;
         return r;
     };
@@ -1913,22 +1945,25 @@ static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const 
     for (int i = nl - 1; i >= 0; --i) {
         const tpz_layer& L = m->layers[i].L;
         Rect R = need[L.dst];
-        if (!R.on) { need.clear(); return need; }            // a tensor nobody reads: leave the program alone
+        if (!R.on) { return bail(6); }            // a tensor nobody reads: leave the program alone
         if (L.op == TPZ_OP_CONV) {
             // launch windows start and end on even pixels: the per-parity kernels work on the half-resolution lattice, a
             // fused max-pool pairs rows and columns
             R.y0 &= ~1; R.x0 &= ~1;
             R.y1 = std::min(Hs[L.dst], (R.y1 + 1) & ~1); R.x1 = std::min(Ws[L.dst], (R.x1 + 1) & ~1);
+            if (dims == 3) { R.z0 &= ~1; R.z1 = std::min(Ds[L.dst], (R.z1 + 1) & ~1); }
             need[L.dst] = R;
             const int g = L.src2 >= 0 ? L.src2 : L.src, span = L.dil * (L.k - 1);
             Rect G;                                           // in the coordinates of the (upsampled) input grid
             G.y0 = R.y0 - L.pad; G.x0 = R.x0 - L.pad; G.y1 = R.y1 - L.pad + span; G.x1 = R.x1 - L.pad + span;
+            if (dims == 3) { G.z0 = R.z0 - L.pad; G.z1 = R.z1 - L.pad + span; }
             G = clip(G, g);
             if (L.src2 >= 0) {
                 need[L.src2].unite(G);
                 Rect S;                                       // the first source, nearest-upsampled to the grid of the second
                 S.y0 = nearest_src_host(G.y0, Hs[L.src], Hs[g]); S.y1 = nearest_src_host(G.y1 - 1, Hs[L.src], Hs[g]) + 1;
                 S.x0 = nearest_src_host(G.x0, Ws[L.src], Ws[g]); S.x1 = nearest_src_host(G.x1 - 1, Ws[L.src], Ws[g]) + 1;
+                if (dims == 3) { S.z0 = nearest_src_host(G.z0, Ds[L.src], Ds[g]); S.z1 = nearest_src_host(G.z1 - 1, Ds[L.src], Ds[g]) + 1; }
                 need[L.src].unite(clip(S, L.src));
             } else {
                 need[L.src].unite(G);
@@ -1936,18 +1971,28 @@ static std::vector<Rect> need_regions(const tpz_model* m, int H0, int W0, const 
             if (L.res >= 0) {
                 Rect Q = R;
                 Q.y0 += L.res_crop; Q.y1 += L.res_crop; Q.x0 += L.res_crop; Q.x1 += L.res_crop;
+                if (dims == 3) { Q.z0 += L.res_crop; Q.z1 += L.res_crop; }
                 need[L.res].unite(clip(Q, L.res));
             }
         } else if (L.op == TPZ_OP_MAXPOOL2) {
             Rect Q;
             Q.y0 = 2 * R.y0; Q.x0 = 2 * R.x0; Q.y1 = 2 * R.y1; Q.x1 = 2 * R.x1;
+            if (dims == 3) { Q.z0 = 2 * R.z0; Q.z1 = 2 * R.z1; }
             need[L.src].unite(clip(Q, L.src));
         } else {
             Rect Q = R;
             Q.y1 += L.dil * (L.k - 1); Q.x1 += L.dil * (L.k - 1);
+            if (dims == 3) Q.z1 += L.dil * (L.k - 1);
             need[L.src].unite(clip(Q, L.src));
         }
     }
+    if (g_trace_host)
+        for (int i = 0; i < nl; ++i) {
+            const tpz_layer& L = m->layers[i].L;
+            const Rect& r = need[L.dst];
+            fprintf(stderr, "[tpz host] need_regions: layer %d op %d -> slot %d: z [%d, %d) of %d, y [%d, %d) of %d, x [%d, %d) of %d\n", i,
+                    (int)L.op, L.dst, r.z0, r.z1, Ds[L.dst], r.y0, r.y1, Hs[L.dst], r.x0, r.x1, Ws[L.dst]);
+        }
     return need;
 }
 
@@ -1957,7 +2002,7 @@ static int run_program(tpz_model* m, std::vector<Slot>& slots, float* d_out, con
     const int nl = (int)m->layers.size();
     slots.resize(std::max<size_t>(slots.size(), (size_t)m->n_slots));
     std::vector<Rect> need;
-    if (keep && slots[0].set && slots[0].D == 1) need = need_regions(m, slots[0].H, slots[0].W, *keep, split);
+    if (keep && slots[0].set) need = need_regions(m, slots[0].D, slots[0].H, slots[0].W, *keep, split);
     int rc = 0;
     for (int i = 0; i < nl && rc == 0; ++i) {
         const LayerRT& rt = m->layers[i];
@@ -2757,9 +2802,13 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
                 if (e != hipSuccess) { rc = fail(ctx, "extract_tile3d failed: %s", hipGetErrorString(e)); break; }
                 Slot tv;
                 set_dense(tv, tile, 1, d, d, d);
-                rc = denoise_region(m, tv, tout, 2, g, split);
-                if (rc) break;
+                // only the centre of the tile is kept (below): every layer computes the box those voxels depend on (need_regions)
                 const int pz = std::min(patch, D - i), py = std::min(patch, H - j), px = std::min(patch, W - k);
+                Rect keep;
+                keep.z0 = pad; keep.z1 = pad + pz; keep.y0 = pad; keep.y1 = pad + py; keep.x0 = pad; keep.x1 = pad + px;
+                keep.on = pad > 0;
+                rc = denoise_region(m, tv, tout, 2, g, split, &keep);
+                if (rc) break;
                 {
                     const float* src_ = tout + ((size_t)pad * d + pad) * d + pad;
                     float* dst_ = d_out + ((size_t)i * H + j) * W + k;
