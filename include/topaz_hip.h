@@ -245,7 +245,10 @@ long long tpz_prof_launches(tpz_ctx* ctx);
  * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the
  * U-Net's receptive field is ~230 pixels, the CLI's default padding 500).  The statistics of the normalisation are still the
  * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
- * (TPZ_NO_ROI=1 in the environment or on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones. */
+ * (TPZ_NO_ROI=1 in the environment or on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones.
+ * The tiles of tpz_denoise_3d (denoise.py:340-377: patch^3 voxels kept of a (patch + 2*padding)^3 tile, 1/8 at the CLI's 96 / 48)
+ * are windowed the same way with boxes, on the 2xf16 kernels (the fp32 kernels compute whole tiles): 3.5x on a 512x512x256
+ * tomogram, bit-identical. */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
 /* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
  * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next
