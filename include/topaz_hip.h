@@ -238,8 +238,12 @@ int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
  * ones: profiles/r04_batch_lanes_ab.txt).  Default n = 8 (TPZ_BATCH=n, TPZ_NO_BATCH=1 in the environment); n = 0: off -- single
  * patches then alternate on the lanes, as do the fp32 kernels (exact mode, overflow re-run) always.  Results are bit-identical
  * either way.
+ * Every image of a batch has a workspace of its own and two batches are in flight: the batch is cut to what fits 90 % of the
+ * free device memory (tpz_ctx_set_batch_memory(ctx, bytes): that many bytes instead; 0 = automatic), below 2 the pass falls
+ * back to single patches on the lanes -- a large tile costs launches, not an out-of-memory error.
  * tpz_prof_launches: kernel launches the library has issued on this context (convolutions, elementwise, NMS sweeps excluded). */
 int tpz_ctx_set_batch(tpz_ctx* ctx, int n);
+int tpz_ctx_set_batch_memory(tpz_ctx* ctx, long long bytes);
 long long tpz_prof_launches(tpz_ctx* ctx);
 /* Patch windows: a patch of tpz_denoise_2d keeps only its centre (topaz/denoise.py:299-323: patch_size pixels of a
  * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the

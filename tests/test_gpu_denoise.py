@@ -281,6 +281,33 @@ def test_tomogram_tiles_sharded_like_ranks_would(gpu_ctx):
         dm.denoise_3d(tomo, -1, 0, shard=0, n_shards=2)
 
 
+def test_batch_is_cut_to_the_memory_it_may_take(gpu_ctx):
+    """every image of a batch has a workspace of its own (runtime.hip batch_that_fits): with no memory to spend the pass falls
+    back to single patches on the lanes -- the launch count of tpz_ctx_set_batch(0), the same bits -- instead of failing"""
+    from topaz_amd.denoise import Denoise
+    d = Denoise('unet-small')
+    x = (np.random.RandomState(79).randn(700, 900) * 3 + 1).astype(np.float32)
+
+    def run():
+        n0 = gpu_ctx.launches()
+        y = d.denoise(x, 200, 120)
+        return y, gpu_ctx.launches() - n0
+    try:
+        y8, n8 = run()
+        gpu_ctx.set_batch_memory(1)
+        y_none, n_none = run()
+        gpu_ctx.set_batch_memory(1 << 42)
+        y_all, n_all = run()
+        gpu_ctx.set_batch_memory(0)
+        gpu_ctx.set_batch(0)
+        y0, n0 = run()
+    finally:
+        gpu_ctx.set_batch(8)
+        gpu_ctx.set_batch_memory(0)
+    assert n_none == n0 > n8 == n_all, (n8, n_none, n_all, n0)
+    assert np.array_equal(y8, y_none) and np.array_equal(y8, y_all) and np.array_equal(y8, y0)
+
+
 @pytest.mark.parametrize('case', ['golden_nf8', 'nf48_ragged', 'nf48_odd_levels', 'nf48_96_48'])
 def test_tile_windows_3d_are_bit_identical(gpu_ctx, case):
     """Denoise3D keeps the centre patch^3 of every (patch + 2*padding)^3 tile (denoise.py:340-377; 1/8 of the tile at the CLI's

@@ -77,6 +77,7 @@ _SIGNATURES = {
     'tpz_ctx_set_exact': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_lanes': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_batch': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_batch_memory': (C.c_int, [_P, C.c_longlong]),
     'tpz_ctx_set_range': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_raster': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_tiling': (C.c_int, [_P, C.c_longlong, C.c_int]),

@@ -152,6 +152,7 @@ struct tpz_ctx {
     std::vector<RecOp> rec[tpz::SPLIT_MULTI_MAX];
     std::vector<Buf> rec_pools[TPZ_N_LANES][tpz::SPLIT_MULTI_MAX];   // per lane (two batches are in flight at a time) and image
     int rec_lane = 0;
+    long long batch_mem = 0;                  // tpz_ctx_set_batch_memory: device bytes a batched pass may take (0: what is free)
     long long n_launches = 0;                 // kernel launches issued (tpz_prof_launches)
     double* d_part = nullptr;     // reduction partials
     float* d_nrm = nullptr;       // ring of float[4] normalisation parameter blocks
@@ -2516,6 +2517,11 @@ int tpz_ctx_set_batch(tpz_ctx* ctx, int n) {
     ctx->batch = n == 1 ? 0 : n;
     return 0;
 }
+int tpz_ctx_set_batch_memory(tpz_ctx* ctx, long long bytes) {
+    if (!ctx || bytes < 0) return fail(ctx, "tpz_ctx_set_batch_memory: bytes >= 0 (0: 90 %% of the free device memory)");
+    ctx->batch_mem = bytes;
+    return 0;
+}
 long long tpz_prof_launches(tpz_ctx* ctx) { return ctx ? ctx->n_launches : 0; }
 
 int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups) {
@@ -2637,6 +2643,49 @@ int tpz_conv_split_2d(tpz_ctx* ctx, const float* d_in, int cin, int H, int W, co
 // ---- denoising ---------------------------------------------------------------------------------
 // Denoise._denoise on a (strided) region: mean / unbiased std -> normalise -> network -> un-normalise.
 // mode 1: plain; mode 2: the un-normalisation also applies the volume's std*y+mu with g = {mu, std}.
+// How many patches / tiles a batched pass may hold at a time.  Every image of a batch lives on a workspace pool of its own and
+// two batches are in flight (one per lane): at the CLI's defaults that is 16 x 4.5 GB for a tomogram and 16 x 2 GB for a
+// micrograph -- nothing on 288 GB -- but a 384^3 tile is 8x that.  The batch is cut to what fits 90 % of the free device memory
+// (+ what the pools already hold), counting for one image every tensor the program allocates (no reuse: an upper bound);
+// below 2 the pass falls back to single patches on the lanes.
+static int batch_that_fits(tpz_ctx* ctx, const tpz_model* m, int D, int H, int W) {
+    if (ctx->batch < 2) return ctx->batch;
+    struct S { int C, D, H, W; };
+    std::vector<S> s(m->n_slots, S{0, 0, 0, 0});
+    s[0] = {1, D, H, W};
+    double per = 3.0 * 4.0 * D * H * W;                          // the tile, its normalised copy, the result
+    for (auto& rt : m->layers) {
+        const tpz_layer& L = rt.L;
+        const S& g = L.src2 >= 0 ? s[L.src2] : s[L.src];
+        if (L.op == TPZ_OP_CONV) {
+            const int span = L.dil * (L.k - 1);
+            s[L.dst] = {L.head ? 1 : L.cout, L.dims == 3 ? g.D + 2 * L.pad - span : 1, g.H + 2 * L.pad - span, g.W + 2 * L.pad - span};
+            if (L.cin == 1 || L.cout == 1) per += 32.0 * ((L.k + 7) / 8) * (double)g.D * g.H * g.W;   // column-kernel copies
+        } else if (L.op == TPZ_OP_MAXPOOL) {
+            const int span = L.dil * (L.k - 1);
+            s[L.dst] = {g.C, L.dims == 3 ? g.D - span : 1, g.H - span, g.W - span};
+        } else {
+            s[L.dst] = {g.C, L.dims == 3 ? g.D / 2 : 1, g.H / 2, g.W / 2};
+        }
+        const S& o = s[L.dst];
+        if (o.D < 1 || o.H < 1 || o.W < 1) return ctx->batch;     // (the pass itself reports the bad geometry)
+        per += 32.0 * split_cells(o.C) * (double)o.D * o.H * o.W;
+    }
+    double avail = (double)ctx->batch_mem;
+    if (ctx->batch_mem <= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return ctx->batch;
+        size_t cached = 0;
+        for (auto& lane_pools : ctx->rec_pools)
+            for (auto& rp : lane_pools)
+                for (auto& b : rp) cached += b.bytes;
+        avail = 0.9 * ((double)free_b + (double)cached);
+    }
+    const int lanes = ctx->lanes_enabled ? ctx->n_lanes : 1;
+    const int fit = (int)std::min<double>(ctx->batch, avail / (per * lanes));
+    return fit >= 2 ? fit : 0;
+}
+
 static int denoise_region(tpz_model* m, const Slot& view, float* d_out_dense, int mode = 1,
                           const float* d_g = nullptr, bool split = false, const Rect* keep = nullptr) {
     tpz_ctx* ctx = m->ctx;
@@ -2673,7 +2722,8 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
     }
     // the patches are independent: on the 2xf16 path they run in batches (the same layer of `batch` patches in one launch:
     // rec_begin / rec_flush), otherwise alternating on the patch lanes
-    const bool batched = split && ctx->batch >= 2;
+    const int batch = split ? batch_that_fits(ctx, m, 1, std::min(H, patch + 2 * pad), std::min(W, patch + 2 * pad)) : 0;
+    const bool batched = batch >= 2;
     if (lanes_begin(ctx)) return 1;
     int rc_all = 0, n_patch = 0, slot = 0, slots_left = 0, n_batches = 0;
     for (int i = 0; i < H && !rc_all; i += patch)
@@ -2682,7 +2732,7 @@ static int denoise_2d_pass(tpz_model* m, const float* d_in, int H, int W, int pa
                 if (slots_left == 0) {
                     if (ctx->rec_on && rec_flush(ctx)) { rc_all = 1; break; }
                     rec_begin(ctx, n_batches++);
-                    slots_left = ctx->batch;
+                    slots_left = batch;
                     slot = 0;
                 }
                 rec_select(ctx, slot++);
@@ -2758,11 +2808,12 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
     const int d = patch + 2 * pad;
     const size_t tn = (size_t)d * d * d;
     // the tiles are independent: batches of `batch` tiles on the 2xf16 path (as the patches of denoise_2d_pass), else the lanes
-    const bool batched = split && ctx->batch >= 2;
+    const int batch = split ? batch_that_fits(ctx, m, d, d, d) : 0;
+    const bool batched = batch >= 2;
     if (lanes_begin(ctx)) return 1;
     // an instance = one tile in flight: (lane, image of the batch) when batched, a lane otherwise
     const int lanes_used = ctx->lanes_on ? ctx->lanes_live : 1;
-    const int per_lane = batched ? ctx->batch : 1;
+    const int per_lane = batched ? batch : 1;
     const int n_inst = lanes_used * per_lane;
     float *tiles[N_LANES * SPLIT_MULTI_MAX] = {}, *touts[N_LANES * SPLIT_MULTI_MAX] = {};
     int rc = 0;
@@ -2788,7 +2839,7 @@ static int denoise_3d_pass(tpz_model* m, const float* d_in, int D, int H, int W,
                     if (slots_left == 0) {
                         if (ctx->rec_on && rec_flush(ctx)) { rc = 1; break; }
                         rec_begin(ctx, n_batches++);
-                        slots_left = ctx->batch;
+                        slots_left = batch;
                         slot = 0;
                     }
                     l = ctx->rec_lane * per_lane + slot++;

@@ -75,6 +75,10 @@ class Context:
         """patches / tiles per batched launch of tpz_denoise_2d / _3d on the 2xf16 path (0: off, the patch lanes instead)"""
         check(self.lib.tpz_ctx_set_batch(self.handle, int(n)), self.handle)
 
+    def set_batch_memory(self, nbytes: int = 0) -> None:
+        """device bytes a batched denoise pass may take for its per-image workspaces (0: 90 % of the free memory)"""
+        check(self.lib.tpz_ctx_set_batch_memory(self.handle, int(nbytes)), self.handle)
+
     def launches(self) -> int:
         """kernel launches issued on this context so far (convolutions and elementwise)"""
         return int(self.lib.tpz_prof_launches(self.handle))
