@@ -86,6 +86,64 @@ def _cpu_model() -> str:
     return 'unknown'
 
 
+def one_socket_cores():
+    """(physical cores of ONE socket, CPU ids of their first hardware threads) from /proc/cpuinfo, restricted to the CPUs this
+    process may run on -- BASELINE.md 3 / SURVEY 8(d) time the CPU path on the physical cores of one socket.  (None, None) where
+    the topology cannot be read."""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = None
+    cores, cur = {}, {}
+    try:
+        for line in list(open('/proc/cpuinfo')) + ['\n']:
+            if ':' in line:
+                k, v = line.split(':', 1)
+                cur[k.strip()] = v.strip()
+            elif cur:
+                if 'processor' in cur and 'physical id' in cur and 'core id' in cur:
+                    cpu = int(cur['processor'])
+                    if allowed is None or cpu in allowed:
+                        cores.setdefault(int(cur['physical id']), {}).setdefault(int(cur['core id']), cpu)
+                cur = {}
+    except (OSError, ValueError):
+        return None, None
+    if not cores:
+        return None, None
+    sock = max(cores, key=lambda k: len(cores[k]))
+    return len(cores[sock]), sorted(cores[sock].values())
+
+
+class OneSocket:
+    """torch's intra-op pool on the physical cores of one socket for the CPU-baseline legs (the main thread and the pool's
+    workers are pinned to them; restored afterwards).  `.cores` = the threads actually used."""
+
+    def __enter__(self):
+        self.prev_threads = torch.get_num_threads()
+        self.prev_aff = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
+        n, cpus = one_socket_cores()
+        self.cores = n or self.prev_threads
+        self.pinned = False
+        if n:
+            torch.set_num_threads(n)
+            try:
+                from topaz_amd.parallel import _set_affinity_all_threads
+                _set_affinity_all_threads(cpus)
+                self.pinned = True
+            except OSError:
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.prev_threads)
+        if self.pinned and self.prev_aff is not None:
+            try:
+                from topaz_amd.parallel import _set_affinity_all_threads
+                _set_affinity_all_threads(sorted(self.prev_aff))
+            except OSError:
+                pass
+
+
 def cpu_baseline(models, args):
     """The oracle (torch-CPU convs, C NMS) timed on this host.  Default: a bounded sample of the step's own units of work --
     the denoiser on ONE full patch of the -s/-p tiling (2024^2 at the defaults; a 4096^2 micrograph is 16 such crops, 3.0x the
@@ -97,7 +155,14 @@ def cpu_baseline(models, args):
     from oracle import scoring as oscoring
     full = args.cpu_full
     img = np.random.RandomState(1000).randn(args.size, args.size).astype(np.float32)
-    threads = torch.get_num_threads()
+    with OneSocket() as sock:
+        return _cpu_baseline(models, args, full, img, sock.cores, sock.pinned)
+
+
+def _cpu_baseline(models, args, full, img, threads, pinned):
+    from oracle import denoising as oden
+    from oracle import nms as onms
+    from oracle import scoring as oscoring
     per_image = 0.0
     parts = {}
     full_px = float(args.size) ** 2
@@ -127,6 +192,9 @@ def cpu_baseline(models, args):
     if 'score' in models:
         sd = models['score'][1]
         oscoring.score('resnet8', sd, img[:256, :256].copy())
+        if not full and S > args.cpu_score_sample:
+            S = args.cpu_score_sample          # (bounds the leg on one socket's cores; 1536^2 runs at the large-image rate)
+            x = x[:S, :S].copy()
         t0 = time.time(); logit = oscoring.score('resnet8', sd, x); t = time.time() - t0
         parts['score_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
@@ -134,11 +202,22 @@ def cpu_baseline(models, args):
         parts['nms_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
     sample = (f'micrograph 0 at {S}x{S} (the whole workload of one step, nothing scaled), times {parts}' if full else
-              f'a {S}x{S} crop of micrograph 0 (one patch of the denoise tiling) through the oracle, times {parts}, each stage '
-              f'scaled by the pixels a {args.size}x{args.size} micrograph pushes through it')
+              f'one patch of the denoise tiling of micrograph 0 ({parts.get("denoise_patch", "-")}) through the oracle U-Net, a '
+              f'{S}x{S} crop of its result through the oracle scorer + C NMS, times {parts}, each stage scaled by the pixels a '
+              f'{args.size}x{args.size} micrograph pushes through it')
     return {'value': 1.0 / per_image, 'unit': 'micrographs/s', 'cores': threads, 'kind': 'port',
+            'cores_are': 'the physical cores of one socket (one torch intra-op thread per core, pinned)' if pinned else
+                         'torch intra-op threads (socket topology not readable: unpinned)',
             'cpu': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
             'sample': sample + '; oracle = torch-CPU fp32 convs (oneDNN), C NMS'}
+
+
+def kernel_source_sha1() -> str:
+    import hashlib
+    try:
+        return hashlib.sha1(open(os.path.join(ROOT, 'topaz_amd', 'csrc', 'conv_split.h'), 'rb').read()).hexdigest()
+    except OSError:
+        return ''
 
 
 def measured_traffic(dom_name: str, args):
@@ -153,9 +232,14 @@ def measured_traffic(dom_name: str, args):
         return None, None
     if rec.get('kernel') != dom_name or rec.get('size') != args.size or rec.get('workload') != args.workload:
         return None, None
+    # ... and was profiled on THIS kernel source: the file records the sha1 of csrc/conv_split.h at the profiled commit
+    if rec.get('conv_split_h_sha1') != kernel_source_sha1():
+        return None, {'stale': True, 'profiled_at_commit': rec.get('profiled_at_commit'),
+                      'reason': 'profiles/pmc_dominant.json was collected on another version of csrc/conv_split.h '
+                                '(re-run tools/pmc_traffic.py)'}
     return rec.get('traffic_bytes_per_launch'), {k: rec.get(k) for k in (
         'fetch_bytes_raw', 'fetch_bytes_corrected', 'write_bytes', 'algorithmic_bytes', 'source', 'correction',
-        'profiled_at_commit')}
+        'profiled_at_commit', 'conv_split_h_sha1')}
 
 
 def dry_run(args, rank, world):
@@ -290,7 +374,11 @@ class GpuSampler:
 
 # the reference's own layer FLOP (2 * Cout * Cin * k^dims * output pixels, every patch / tile in full) of the BASELINE configs
 CONFIG_TFLOP = {'c2_extract_resnet8_u64': 44.23, 'c2_extract_resnet8_u32': 11.09, 'c3_denoise_unet_patched': 29.06,
-                'c3_denoise_unet_whole': 9.68, 'c5_denoise3d_unet3d': 516.7}
+                'c3_denoise_unet_whole': 9.68, 'c5_denoise3d_unet3d': 516.7,
+                # not BASELINE configs, but what users run: `topaz extract` defaults to -m resnet16 (commands/extract.py:16-53,
+                # factory.py:36-51 = units 64; resnet16_u32 is the shipped blob) and north_star names Conv127 (factory.py:15-17);
+                # TFLOP per 4096^2 micrograph from SURVEY.md 8(d)
+                'extract_resnet16_u64': 61.99, 'extract_resnet16_u32': 15.53, 'extract_conv127_u32': 3.61}
 
 
 def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
@@ -340,6 +428,22 @@ def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
     dn = models['denoise'][0] if 'denoise' in models else None
     measure('c2_extract_resnet8_u64', scorer(m64))
     measure('c2_extract_resnet8_u32', scorer(u32))
+    # the detectors users actually run: the CLI default resnet16 (u64, seeded: blob missing upstream), the
+    # shipped resnet16_u32, conv127 (u32, BN + PReLU, seeded); each with its three heaviest kernels
+    from topaz_amd.model.classifier import LinearClassifier
+    m16, sd16 = sw.hip_resnet('resnet16', 64, seed=7)
+    r16u32 = load_model('resnet16_u32')
+    r16u32.eval(); r16u32.fill(); r16u32.cuda()
+    sd127 = sw.basic_sd((7, 5, 5, 5, 5), 32, 7)
+    c127 = LinearClassifier('conv127', sd127)
+    c127.eval(); c127.fill(); c127.cuda()
+    for key, m in (('extract_resnet16_u64', m16), ('extract_resnet16_u32', r16u32), ('extract_conv127_u32', c127)):
+        measure(key, scorer(m))
+        rows = sorted(ctx.prof_kernels(), key=lambda r: -r[1])[:3]        # (the profiled call of measure(): every launch timed)
+        out[key]['top_kernels'] = [{'kernel': nm, 'ms': ms, 'launches': n, 'tflops': fl / ms / 1e9,
+                                    'frac': fl / ms / 1e9 / SPLIT_PEAK_TFLOPS} for nm, ms, n, fl in rows if ms > 0]
+        n_conv, n_split, off = m.device_model.split_layers()
+        out[key]['layers_on_2xf16_path'] = f'{n_split} of {n_conv}'
     if dn is not None:
         measure('c3_denoise_unet_patched', lambda: dn.denoise_device(x, args.patch_size, args.patch_padding))
         measure('c3_denoise_unet_whole', lambda: dn.denoise_device(x, -1, 0))
@@ -356,18 +460,20 @@ def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
     measure('c5_denoise3d_unet3d', lambda: d3.model.device_model.denoise_3d(tomo, 96, 48), n=1)
     out['c5_denoise3d_unet3d']['unit'] = 'one 512x512x256 tomogram, 96/48 tiles (108 tiles of 192^3)'
     del tomo
-    for k in ('c2_extract_resnet8_u64', 'c2_extract_resnet8_u32', 'c3_denoise_unet_patched', 'c3_denoise_unet_whole'):
+    for k in ('c2_extract_resnet8_u64', 'c2_extract_resnet8_u32', 'c3_denoise_unet_patched', 'c3_denoise_unet_whole',
+              'extract_resnet16_u64', 'extract_resnet16_u32', 'extract_conv127_u32'):
         if k in out:
             out[k]['unit'] = f'one {S}x{S} micrograph'
-    if with_cpu:
-        # the oracle on a bounded sample of each config, scaled by the pixels / voxels the whole unit pushes through the net
+    def cpu_legs(sock):
+        # the oracle on a bounded sample of each config, scaled by the pixels / voxels the whole unit pushes through the net,
+        # on the physical cores of one socket (OneSocket)
         P = 1024
         crop = np.random.RandomState(1000).randn(P, P).astype(np.float32)
         full_px = float(S) * S
 
         def cpu(key, seconds, scale, sample):
             if key in out:
-                out[key]['cpu_baseline'] = {'ms': 1e3 * seconds * scale, 'kind': 'port', 'cores': torch.get_num_threads(),
+                out[key]['cpu_baseline'] = {'ms': 1e3 * seconds * scale, 'kind': 'port', 'cores': sock.cores,
                                             'sample': sample, 'gpu_over_cpu': seconds * scale / (out[key]['ms'] * 1e-3)}
         sdu = {k: v.numpy() for k, v in u32.state_dict().items()}
         oscoring.score('resnet8', sdu, crop[:256, :256].copy())
@@ -376,6 +482,12 @@ def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
         if sd64 is not None:
             t0 = time.time(); lg = oscoring.score('resnet8', sd64, crop); onms.nms2d(lg, args.radius, args.threshold); t = time.time() - t0
             cpu('c2_extract_resnet8_u64', t, full_px / (P * P), f'{P}x{P} crop through the oracle scorer + C NMS, scaled by pixels')
+        for key, arch, sdx in (('extract_resnet16_u64', 'resnet16', sd16),
+                               ('extract_resnet16_u32', 'resnet16', {k: v.numpy() for k, v in r16u32.state_dict().items()}),
+                               ('extract_conv127_u32', 'conv127', sd127)):
+            oscoring.score(arch, sdx, crop[:256, :256].copy())
+            t0 = time.time(); lg = oscoring.score(arch, sdx, crop); onms.nms2d(lg, args.radius, args.threshold); t = time.time() - t0
+            cpu(key, t, full_px / (P * P), f'{P}x{P} crop through the oracle scorer + C NMS, scaled by pixels')
         if dn is not None:
             sd = models['denoise'][1]
             oden.denoise('unet', sd, crop[:256, :256].copy(), -1)
@@ -395,7 +507,29 @@ def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
         t0 = time.time(); oden.denoise_whole('unet-3d', tsd3, vol); t = time.time() - t0
         cpu('c5_denoise3d_unet3d', t, 108.0 * 192 ** 3 / float(T ** 3), f'one {T}^3 tile through the oracle 3-D U-Net, scaled to the '
             '108 tiles of 192^3 voxels the reference computes')
+
+    if with_cpu:
+        with OneSocket() as sock:
+            cpu_legs(sock)
     return out
+
+
+def blob_micrograph(S: int, seed: int, spacing: int = 36, sigma: float = 6.0, amp: float = 2.5, jitter: int = 5):
+    """N(0,1) noise over a jittered grid of dark Gaussian blobs ("particles"): after denoising, the pretrained detector finds
+    ~1 100 picks per Mpx at r = 14, t = -6 (oracle chain on a 640^2 crop: 466 picks for 256 blobs), so that the extract half
+    of the CLI leg really produces, gathers and writes a pick table (pure noise denoises to a flat map: 0 picks)."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(S, S).astype(np.float32)
+    R = int(4 * sigma)
+    yy, xx = np.mgrid[-R:R + 1, -R:R + 1].astype(np.float32)
+    stamp = (amp * np.exp(-(yy ** 2 + xx ** 2) / (2 * sigma ** 2))).astype(np.float32)
+    n = 0
+    for cy in range(spacing // 2 + R, S - R - spacing // 2, spacing):
+        for cx in range(spacing // 2 + R, S - R - spacing // 2, spacing):
+            y, xq = cy + rs.randint(-jitter, jitter + 1), cx + rs.randint(-jitter, jitter + 1)
+            x[y - R:y + R + 1, xq - R:xq + R + 1] -= stamp
+            n += 1
+    return x, n
 
 
 def cli_inclusive(args, dev, n=6):
@@ -422,7 +556,7 @@ def cli_inclusive(args, dev, n=6):
         src = []
         for i in range(n):
             p = os.path.join(d, f'mic_{i:03d}.mrc')
-            save_image(np.random.RandomState(3000 + i).randn(S, S).astype(np.float32), p)
+            save_image(blob_micrograph(S, 3000 + i)[0], p)
             src.append(p)
         den_dir = os.path.join(d, 'den')
         sink = io.StringIO()
@@ -441,8 +575,11 @@ def cli_inclusive(args, dev, n=6):
             c0, c1, c2 = both()          # first invocation in the process: also grows the workspace pools and the staging rings
             t0, t1, t2 = both()
         n_picks = sum(1 for _ in open(os.path.join(d, 'picks.txt'))) - 1
+        if S >= 2048 and n_picks <= 10000 * n * (S / 4096.0) ** 2:
+            raise RuntimeError(f'cli_inclusive: only {n_picks} picks over {n} micrographs -- the extract half of the leg is not '
+                               'exercising NMS output, the gather and the writer')
         # the same networks on a resident micrograph
-        x = torch.randn(S, S, device=dev)
+        x = torch.from_numpy(blob_micrograph(S, 3000)[0]).to(dev)
         tl = time.perf_counter()
         dn = Denoise('unet-v0.2.1')
         m = load_model('resnet8_u32')
@@ -465,6 +602,9 @@ def cli_inclusive(args, dev, n=6):
                 'denoise_ms_per_micrograph': 1e3 * (t1 - t0) / n, 'extract_ms_per_micrograph': 1e3 * (t2 - t1) / n,
                 'first_invocation_ms_per_micrograph': 1e3 * (c2 - c0) / n,
                 'gpu_only_ms_per_micrograph': gpu_ms, 'model_loading_ms_per_job': load_ms, 'picks': n_picks,
+                'picks_per_micrograph': n_picks / n,
+                'input': 'N(0,1) noise over a jittered 36-px grid of dark Gaussian blobs (sigma 6, amplitude 2.5): particles for the '
+                         'pretrained detector to find after denoising',
                 'io_mb_per_micrograph': {'read': 2 * mb, 'written': mb},
                 'where': d if base is None else 'tmpfs (/dev/shm)',
                 'note': 'topaz denoise -m unet-v0.2.1 -> topaz extract -m resnet8_u32 through topaz_amd.main in this process, model '
@@ -494,6 +634,7 @@ def main():
     ap.add_argument('--radius', type=int, default=14)
     ap.add_argument('--threshold', type=float, default=-6.0)
     ap.add_argument('--cpu-sample', type=int, default=2048)
+    ap.add_argument('--cpu-score-sample', type=int, default=1536, help='cpu_baseline: crop the scorer + NMS are timed on')
     ap.add_argument('--cpu-full', action='store_true', help='cpu_baseline on one whole micrograph instead of a crop (minutes)')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -549,7 +690,20 @@ def main():
     sampler = GpuSampler(local_rank)
     sampler.__enter__()                                  # (joined after the timed region: its 25 ms sleep is not part of the job)
     t0 = time.perf_counter()
-    picks = [run_step(models, imgs[i % n_res], args) for i in range(args.steps)]
+    step_t, mem_used = [], {}
+    if args.scaling == 'strong':
+        # the fixed job as a SOAK through the real job path: every step's completion time (a step ends with
+        # the suppression's host read of the pick count, so the host clock is the step's clock) and the device memory in use
+        # after the first steps / at the end -- the workspace pools must not grow once they are warm
+        picks = []
+        for i in range(args.steps):
+            picks.append(run_step(models, imgs[i % n_res], args))
+            step_t.append(time.perf_counter())
+            if i in (min(args.steps, 8) - 1, args.steps - 1):
+                free_b, total_b = torch.cuda.mem_get_info(dev)
+                mem_used[i] = total_b - free_b
+    else:
+        picks = [run_step(models, imgs[i % n_res], args) for i in range(args.steps)]
     torch.cuda.synchronize(dev)
     t_compute = time.perf_counter() - t0
     sampler._stop = True
@@ -806,6 +960,21 @@ def main():
             },
             **extras,
         }
+        if step_t:
+            n = len(step_t)
+            w = min(32, n // 2) or 1
+            d_ms = [1e3 * (b - a) for a, b in zip([t0] + step_t[:-1], step_t)]
+            ks = sorted(mem_used)
+            out['soak'] = {
+                'images': n, 'first_ms_per_step': sum(d_ms[:w]) / w, 'last_ms_per_step': sum(d_ms[-w:]) / w, 'window': w,
+                'slowest_step_ms': max(d_ms), 'fastest_step_ms': min(d_ms),
+                'device_bytes_in_use_after_step': {str(k + 1): int(mem_used[k]) for k in ks},
+                'pool_growth_bytes_after_warm_up': int(mem_used[ks[-1]] - mem_used[ks[0]]) if len(ks) == 2 else 0,
+                'peak_device_gb': max(mem_used.values()) / 1e9 if mem_used else None,
+                'fp32_reruns': fp32_reruns,
+                'what': f'--scaling strong: the fixed job of {args.images} micrographs ({n} on this rank, cycling through '
+                        f'{n_res} resident inputs) through denoise -> score -> NMS; per-step host clock (each step ends with the '
+                        'host read of its pick count), device memory from hipMemGetInfo'}
         if configs is not None:
             out['configs'] = configs
         if world == 1 and not args.no_cpu_baseline:

@@ -138,6 +138,10 @@ int tpz_gmm_fit(tpz_ctx* ctx, const float* d_x, size_t n, const double* pis, con
                 double* pis_out, double* logps);
 /* y = x*scale + shift  (the (x-mu)/std and std*y+mu steps of topaz/denoise.py:389,414) */
 int tpz_affine(tpz_ctx* ctx, const float* d_x, size_t n, float scale, float shift, float* d_y);
+/* y = (x - mean) / std evaluated as numpy does in `(mic - mu) / std` (topaz/denoise.py:389, :412 and commands/normalize):
+ * fp32 subtraction, then an IEEE fp32 division -- exact low bits on raw-count micrographs (|mean| >> std); std == 0 yields the
+ * reference's inf / nan. */
+int tpz_normalize(tpz_ctx* ctx, const float* d_x, size_t n, float mean, float std, float* d_y);
 /* 1->1 channel 2-D filter with zero "same" padding: GaussianDenoise / InvGaussianFilter /
  * AffineFilter.forward (topaz/filters.py:28-96).  h_w is the [k][k] kernel on the host. */
 int tpz_filter_2d(tpz_ctx* ctx, const float* d_in, int H, int W, const float* h_w, int k, float bias,

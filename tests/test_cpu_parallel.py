@@ -1,6 +1,8 @@
 """gloo tests (world 2 and world 8) of the multi-GPU layer: sharding, the pick-table gather, the launcher, bench.py's ranks."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
@@ -180,6 +182,7 @@ def test_launcher_reads_stdin_once_for_all_ranks(monkeypatch):
     lf = os.path.join(os.path.dirname(__file__), '_tmp_list.txt')
     open(lf, 'w').write('\n'.join(names) + '\n')
     monkeypatch.setenv('TOPAZ_AMD_INPUT_LIST', lf)
+    monkeypatch.setenv('WORLD_SIZE', '1')                     # only a rank process of a launcher honours the variable ...
     got = {}
 
     def fake_score(model, paths, **kw):
@@ -195,6 +198,36 @@ def test_launcher_reads_stdin_once_for_all_ranks(monkeypatch):
     finally:
         os.unlink(lf)
     assert got.get('paths') == names
+    assert 'TOPAZ_AMD_INPUT_LIST' not in os.environ           # ... once (popped: nothing stale is left behind)
+    # outside a launcher an exported / stale variable is ignored: stdin is the list (topaz/extract.py:270)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setenv('TOPAZ_AMD_INPUT_LIST', '/nonexistent/stale_list.txt')
+    monkeypatch.setattr(sys, 'stdin', io.StringIO('a.mrc\nb.mrc\n'))
+    try:
+        ext.extract_particles([], 'resnet8_u32', 0, 1, -6.0, 8, 0, None, 5, 100, 5, -1, 0, False, None, False, '', 'coord', 1.0, 1.0)
+    except KeyboardInterrupt:
+        pass
+    assert got.get('paths') == ['a.mrc', 'b.mrc']
+
+
+def test_cli_exit_status_ignores_command_return_values(monkeypatch):
+    """`topaz denoise` / `denoise3d` return their output / input lists to a Python caller (topaz/denoise.py:463-487, 548);
+    the console script does `raise SystemExit(main())`, so main() must return 0 after a successful command -- a list there
+    prints itself and exits 1, and under `--gpus N` the launcher then kills the ranks still working.  Like topaz/main.py:148."""
+    from topaz_amd import main as tmain
+    from topaz_amd.commands import denoise, denoise3d
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(denoise, 'main', lambda args: ['out/a.mrc', 'out/b.mrc'])
+    monkeypatch.setattr(denoise3d, 'main', lambda args: [])
+    assert tmain.main(['denoise', 'a.mrc', 'b.mrc']) == 0
+    assert tmain.main(['denoise3d', 'a.mrc']) == 0
+    # and through the module entry point: exit status 0, nothing but the command's own output
+    code = ('import sys; from topaz_amd.commands import denoise; denoise.main = lambda a: ["x.mrc"]; '
+            'sys.argv = ["topaz", "denoise", "x.mrc"]; import runpy; runpy.run_module("topaz_amd", run_name="__main__")')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.join(os.path.dirname(__file__), '..'))
+    assert r.returncode == 0, r.stderr[-400:]
+    assert 'x.mrc' not in r.stderr
 
 
 def _sum_worker(rank, world, port, q):

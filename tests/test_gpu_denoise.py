@@ -87,8 +87,15 @@ def test_user_trainable_archs_unet2_unet3_pickles(gpu_ctx, tag):
     import os
     from conftest import GOLDEN
     from topaz_amd.denoise import Denoise
+    import warnings
     z = load_golden(f'denoise2d_{tag}')
-    d = Denoise(os.path.join(GOLDEN, f'user_model_{tag}.sav'))
+    with warnings.catch_warnings():
+        # widths that are not multiples of 16 (nf = 12: sources of 12 + 12 and 24 + 1 channels) are loaded zero-padded to the
+        # next multiple (runtime.hip widen_program): every layer on the 2xf16 path, no mixed-program warning
+        warnings.simplefilter('error')
+        d = Denoise(os.path.join(GOLDEN, f'user_model_{tag}.sav'))
+    n_conv, n_split, off = d.model.device_model.split_layers()
+    assert n_split == n_conv, off
     assert d.model.kind == tag.split('_')[0]
     for exact in (False, True):
         gpu_ctx.set_exact(exact)
@@ -353,6 +360,33 @@ def test_tile_windows_3d_are_bit_identical(gpu_ctx, case):
         assert fl_win == fl_full
     else:
         assert fl_win < (0.4 if case == 'nf48_96_48' else 0.8) * fl_full
+
+
+def test_batched_tiles_with_mixed_source_chunks(gpu_ctx, monkeypatch):
+    """A two-source plane-stacked launch whose chunks mix both tensors (conv_split MODE 3: widths of a user-trained 3-D U-Net
+    whose first source does not fill whole chunks; forced here by TPZ_NO_SRCMAJOR, read when the model is loaded) has no
+    batched instantiation: rec_flush must issue those launches one by one instead of failing the whole batched pass with
+    'conv_split launch failed: invalid value' (round-4 advisor finding).  Same bits as the unbatched lanes path and as the
+    source-major model."""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    z = load_golden('denoise3d_unet3d_nf8')
+    tomo = torch.from_numpy(z['tomo']).cuda()
+    ref = Denoise3D(DenoiseNet('unet-3d', golden_sd(z))).model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()
+    monkeypatch.setenv('TPZ_NO_SRCMAJOR', '1')
+    d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+    monkeypatch.delenv('TPZ_NO_SRCMAJOR')
+    try:
+        gpu_ctx.set_batch(8)
+        batched = d.model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()
+        gpu_ctx.set_batch(0)
+        single = d.model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()
+    finally:
+        gpu_ctx.set_batch(8)
+    assert np.isfinite(batched).all()
+    assert np.array_equal(batched, single)
+    assert _err(batched, ref) <= 2e-6          # (another cell order of the K loop: another summation order)
+    assert _err(batched, z['p32_16']) <= ATOL
 
 
 @pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'ragged', 'unet3d'])

@@ -89,6 +89,41 @@ def test_bench_resnet8_u64_4096_windows_vs_oracle(gpu_ctx):
     print(f'resnet8-u64 4096^2: max |split - oracle| {e_split:.2e}, |fp32 - oracle| {e_f32:.2e}, |split - fp32| {_abs(y, y32):.2e}')
 
 
+def test_cli_default_resnet16_u64_4096_windows_vs_oracle_and_float64(gpu_ctx):
+    """`topaz extract` defaults to -m resnet16 (= 64 units; commands/extract.py:16-53, factory.py:36-51): the deepest network of
+    the path (16 convolutions, K up to 3 200 per sum) and the one with the least headroom under the 1e-4 bar (6.3e-5 against
+    float64 on a 512^2 image, torch fp32 itself 3.6e-5).  At 4096^2 (seeded weights, head calibrated like the pretrained nets:
+    logits about [-25, +8]): windows of the score map -- corners, edges, interior -- against the oracle's fp32 AND float64
+    evaluation of the window's own crop: <= 1e-4 absolute against both, and against float64 no more than 2x what torch's own
+    fp32 evaluation is off by; no fp32 re-run."""
+    from topaz_amd.model.classifier import LinearClassifier
+    sd = oscoring.synthetic_resnet_sd('resnet16', 64, 7)
+    m = LinearClassifier('resnet16', sd)
+    m.eval(); m.fill(); m.cuda()
+    halo = m.width // 2
+    x = np.random.RandomState(1001).randn(4096, 4096).astype(np.float32)
+    dm = m.device_model
+    before = dm.split_stats()
+    y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    after = dm.split_stats()
+    assert after[1] == before[1] + 1 and after[2] == before[2], 'expected one 2xf16 forward without an fp32 re-run'
+    assert y.shape == x.shape and y.min() < -12 and y.max() > -2
+    size, worst, worst64, worst_t = 192, 0.0, 0.0, 0.0
+    for (y0, x0) in ((0, 0), (3904, 3904), (1900, 2100), (0, 2048), (2048, 3904)):
+        ys, xs = max(0, y0 - halo), max(0, x0 - halo)
+        ye, xe = min(4096, y0 + size + halo), min(4096, x0 + size + halo)
+        crop = x[ys:ye, xs:xe]
+        win = lambda a: a[y0 - ys:y0 - ys + size, x0 - xs:x0 - xs + size]
+        ref32, ref64 = win(oscoring.score('resnet16', sd, crop)), win(oscoring.score('resnet16', sd, crop, dtype=torch.float64))
+        got = y[y0:y0 + size, x0:x0 + size]
+        e32, e64, et = _abs(got, ref32), _abs(got, ref64), _abs(ref32, ref64)
+        assert e32 <= ATOL and e64 <= ATOL, (y0, x0, e32, e64)
+        worst, worst64, worst_t = max(worst, e32), max(worst64, e64), max(worst_t, et)
+    print(f'resnet16-u64 4096^2 (halo {halo}): max |2xf16 - oracle fp32| {worst:.2e}, |2xf16 - float64| {worst64:.2e}, '
+          f'|torch fp32 - float64| {worst_t:.2e}')
+    assert worst64 <= 2.0 * worst_t, (worst64, worst_t)
+
+
 def test_bench_unet_nf48_4096_default_patching_vs_oracle_patches(gpu_ctx):
     """unet b11/t5 nf48 (seed 11) with the CLI-default patching on a 4096^2 N(0,1) micrograph (exactly bench.py's
     denoise stage): the centre of a patch equals the oracle's `_denoise` of that patch crop alone (denoise.py:307-322)

@@ -59,6 +59,31 @@ def test_scoring_nets_against_float64(gpu_ctx, arch, units):
     assert rms(y) <= RATIO * rms(ref32)
 
 
+@pytest.mark.parametrize('gain,offset', [(4.0, 2.0), (0.05, 0.0)])
+def test_resnet16_u64_wide_and_narrow_inputs_against_float64(gpu_ctx, gain, offset):
+    """the CLI-default detector on micrographs that are NOT N(0,1) (extract.py:234-249 scores whatever it is given): a wide
+    image (x * 4 + 2: logits several times the usual range, activations up to a few hundred -- still inside f16, so no range
+    scaling: s = 0 up to a 99.9 % quantile of 8) and a faint one (x * 0.05: activations towards the lo halves' absolute floor).
+    Error against float64 <= 2x torch-fp32's, and <= 1e-4 absolute where the logits have the range the bar is stated for."""
+    from topaz_amd.model.classifier import LinearClassifier
+    sd = oscoring.synthetic_resnet_sd('resnet16', 64, 7)
+    m = LinearClassifier('resnet16', sd)
+    m.eval(); m.fill(); m.cuda()
+    x = (np.random.RandomState(1002).randn(400, 432) * gain + offset).astype(np.float32)
+    ref64 = oscoring.score('resnet16', sd, x, dtype=torch.float64)
+    ref32 = oscoring.score('resnet16', sd, x)
+    dm = m.device_model
+    before = dm.split_stats()
+    y = m(torch.from_numpy(x).cuda()[None, None])[0, 0].cpu().numpy()
+    after = dm.split_stats()
+    assert after[2] == before[2], 'no fp32 re-run expected'
+    e, et, scale = _abs(y, ref64), _abs(ref32, ref64), float(np.abs(ref64).max())
+    print(f'resnet16-u64 on x*{gain}+{offset}: |logit| up to {scale:.3g}; vs float64: 2xf16 {e:.2e}, torch fp32 {et:.2e}')
+    assert e <= max(RATIO * et, 2e-6 * scale)
+    if scale <= 30:
+        assert e <= ATOL
+
+
 @pytest.mark.parametrize('net', ['bench-nf48', 'unet-v0.2.1'])
 def test_unet_against_float64(gpu_ctx, net):
     """the bench's seeded U-Net (b11 / t5, 48 filters) and the pretrained v0.2.1 on a 512 x 480 micrograph, whole image

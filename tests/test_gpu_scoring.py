@@ -335,6 +335,8 @@ def test_pooled_resnets_vs_reference_golden(gpu_ctx, name):
     m = LinearClassifier(str(z['arch']), golden_sd(z), pooling=True)
     assert m.width == int(z['width']) and m.fill() == 4
     y = _score(m, z['x0'])
+    n_conv, n_split, off = m.device_model.split_layers()
+    assert n_split == n_conv, off              # (ResNet6's 5x5 stem has a 5 x 1 column kernel: no layer on an fp32 kernel)
     assert y.shape == z['y0'].shape
     assert np.abs(y - z['y0']).max() <= ATOL
     gpu_ctx.set_exact(True)

@@ -53,6 +53,7 @@ _SIGNATURES = {
     'tpz_gmm_fit': (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
                               _P, _P, _P, _P]),
     'tpz_affine': (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    'tpz_normalize': (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     'tpz_filter_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
     'tpz_nms_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     'tpz_nms_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, _P, _P, C.c_int,

@@ -21,7 +21,7 @@ def main(args):
     from .. import parallel
     set_num_threads(args.num_threads)
     _, local_rank, world = parallel.init_from_env()
-    device = local_rank if world > 1 else args.device
+    device = parallel.rank_device(local_rank) if world > 1 else args.device
     use_cuda = set_device(device)
     print(f'# using device={device} with cuda={use_cuda}', file=sys.stderr)
     if (args.dir_a is not None and args.dir_b is not None) or (args.hdf is not None):

@@ -23,7 +23,7 @@ def main(args):
     if args.device == -1:
         print('ERROR: Invalid device id or format', file=sys.stderr)
         sys.exit(1)
-    device = local_rank if (world > 1 or args.device == -2) else args.device
+    device = parallel.rank_device(local_rank) if (world > 1 or args.device == -2) else args.device
     if device >= torch.cuda.device_count():
         print('ERROR: Invalid device id or format', file=sys.stderr)
         sys.exit(1)

@@ -8,3 +8,9 @@
 TPZ_SPLIT(11, 1, 64, 16, 64, 1, ::tpz::EPI_PLAIN)
 TPZ_SPLIT4_COL(11, 1, 64, 8, 32, 1, ::tpz::EPI_PLAIN)
 TPZ_SPLIT4_COL(11, 1, 16, 8, 32, 1, ::tpz::EPI_PLAIN_F32)      // (two cells per chunk would not leave room for two workgroups per CU)
+// 5 x 1 column stems (ResNet6's 5x5 1 -> units first conv, resnet.py:254-277): the kx taps as the 8 channels of one cell
+TPZ_SPLIT4_COL(5, 1, 32, 8, 32, 1, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4_COL(5, 1, 64, 8, 32, 1, ::tpz::EPI_PLAIN)
+// 3 x 1 column stems (a 3x3 first conv of a user-trained stack)
+TPZ_SPLIT4_COL(3, 1, 32, 8, 32, 1, ::tpz::EPI_PLAIN)
+TPZ_SPLIT4_COL(3, 1, 64, 8, 32, 1, ::tpz::EPI_PLAIN)

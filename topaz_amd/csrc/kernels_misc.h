@@ -13,6 +13,7 @@ hipError_t launch_meanstd(const float* x, int D, int H, int W, long long ps, int
 hipError_t launch_gmm_pass(const float* x, size_t n, int mode, const double* d_par, double* d_part, int part_blocks,
                            double* d_out, hipStream_t s);
 hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float shift, hipStream_t s);
+hipError_t launch_normalize(const float* x, float* y, size_t n, float mu, float sd, hipStream_t s);     // y = (x - mu) / sd
 hipError_t launch_affine_dev(const float* x, int D, int H, int W, long long ps, int pitch, const float* d_p, float* y,
                              hipStream_t s);
 hipError_t launch_transpose(const float* in, float* out, int R, int Cc, hipStream_t s);
@@ -25,6 +26,11 @@ hipError_t launch_shiftx_split(const float* in, void* out, int K, int pad, size_
 hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W, int Wp, float bias, const float* nrm,
                            int norm_out, hipStream_t s, size_t y0 = 0, size_t y1 = (size_t)-1, int x0 = 0, int x1 = 0x7fffffff,
                            const float* res = nullptr, int Hp = 0, int z0 = 0, int z1 = 1);   // Hp > 0: planes [z0, z1) of Hp rows
+// 1-output-channel k^dims conv over split cells on the vector ALUs (K = 3 or 5; KZ = K for a 3-D conv, else 1), fused with bias,
+// same-size residual and un-normalisation; wt = [KZ][cells][kx][ky][8] fp32
+hipError_t launch_conv_cout1_split(const void* in, const float* wt, float* out, const float* res, const float* nrm, int norm_out,
+                                   float bias, int cells, int K, int KZ, int D, int H, int W, int z0, int z1, int y0, int y1,
+                                   int x0, int x1, hipStream_t s);
 hipError_t launch_s2d_split(const float* in, void* out, int d, int h, int w, int H, int W, int dims, unsigned* flag,
                             hipStream_t s);
 hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsigned* flag, hipStream_t s);

@@ -421,6 +421,22 @@ hipError_t launch_affine(const float* x, float* y, size_t n, float scale, float 
     return hipGetLastError();
 }
 
+// y = (x - mu) / std in fp32, as numpy evaluates `(mic - mu) / std` (denoise.py:389): the subtraction first -- a raw-count
+// micrograph with |mu| >> std keeps its low bits, which x * (1 / std) + (-mu / std) with two rounded coefficients does not --
+// and an IEEE division (std == 0 gives the reference's inf / nan, not a host exception)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float mu,
+                                                        float sd) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = __fdiv_rn(__fsub_rn(x[i], mu), sd);
+}
+
+hipError_t launch_normalize(const float* x, float* y, size_t n, float mu, float sd, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(normalize_kernel, dim3(blocks), dim3(256), 0, s, x, y, n, mu, sd);
+    return hipGetLastError();
+}
+
 // y[z][y][x] (dense) = x_view[z][y][x]*p[0] + p[1] with p on the device: the (x - mu)/std step of
 // Denoise._denoise (denoise.py:284) applied to a (strided) patch view before the network reads it.
 __global__ __launch_bounds__(256) void affine_dev_kernel(const float* __restrict__ x, int D, int H, int W,
@@ -741,6 +757,142 @@ hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(shiftsum_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, Y, out, K, rows, W, Wp, bias, nrm, norm_out,
                        y0, y1, x0, x1, res, hp, z0, z1);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// 1-output-channel last conv of the denoisers on the 2xf16 path (denoising/models.py:125-128, 238-244, 560-562: Conv(32, 1, k)):
+// split cells in, ONE fp32 plane out.  On the matrix cores this layer is an M = 16 tile with one useful row per kx tap
+// (conv_split_kernel<K x 1, MT = 16>: 26 TFLOP/s, + the shift-sum of its k planes); here it is what it is -- an HBM-bound
+// stencil of cin * k^dims multiply-adds per pixel -- on the vector ALUs in full fp32:
+//   * tile = TH x 64 output pixels per 256-thread workgroup, two workgroups per CU; wave w owns R = TH / 4 consecutive rows,
+//     lane l column l: a lane's 16-byte LDS reads are those of its neighbours shifted by one pixel (conflict-free);
+//   * per (input plane kz, 8-channel cell): the (TH + K - 1) x (64 + K - 1) input pixels of the tile are fetched with buffer
+//     loads (out-of-image = zeros), hi + lo joined ONCE per pixel (exact: the halves carry 22 bits) and stored as fp32,
+//     [half of the cell][row][pixel] x 16 B;
+//   * per kx a lane holds its column of R + K - 1 pixels x 8 channels in registers and runs the K ky taps of its R outputs
+//     over them with v_pk_fma_f32 on channel pairs; the taps' weights ([kz][cell][kx][ky][8] fp32) arrive as scalar loads.
+// A pixel's sum is formed in a fixed order (kz, cell, kx, ky, channel pair) whatever tile or window it falls into: patch
+// windows, batched passes and tile windows stay bit-identical.  Bias, the same-size residual (UDenoiseNet3) and the
+// un-normalisation of Denoise._denoise (denoise.py:291-294) are applied in the same pass: no k-plane scratch tensor, no
+// shift-sum launch.
+// ------------------------------------------------------------------------------------------
+template <int K, int TH>
+__global__ __launch_bounds__(256, 2) void conv_cout1_split_kernel(const uint4* __restrict__ in, const float* __restrict__ wt,
+                                                                  float* __restrict__ out, const float* __restrict__ res,
+                                                                  const float* __restrict__ nrm, int norm_out, float bias,
+                                                                  int cells, int KZ, int D, int H, int W, int pad, int wz0,
+                                                                  int wy0, int wx0, int wy1, int wx1, int tiles_x, int tiles_y) {
+    constexpr int TW = 64, R = TH / 4, IR = R + K - 1, ITH = TH + K - 1, ITW = TW + K - 1;
+    constexpr int HALF = ITH * ITW;                 // 16-byte slots per half-cell plane of the LDS tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float4* const lds = reinterpret_cast<float4*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int z = wz0 + (int)blockIdx.y;
+    const int y0 = wy0 + by * TH, x0 = wx0 + bx * TW;
+    const size_t plane_px = (size_t)H * W, cell_px = (size_t)D * plane_px;
+    const size_t lo_off = (size_t)cells * cell_px;             // cells from a hi cell to its lo cell
+    f32x2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = (f32x2){0.f, 0.f};
+    for (int kz = 0; kz < KZ; ++kz) {
+        const int iz = z + kz - (KZ > 1 ? pad : 0);
+        if ((unsigned)iz >= (unsigned)D) continue;             // (zero padding in z: nothing to add; uniform per workgroup)
+        for (int c = 0; c < cells; ++c) {
+            // ---- stage: cell c of plane iz, rows y0 - pad .. , columns x0 - pad ..  -> fp32 in the LDS
+            const uint4* src = in + ((size_t)c * D + iz) * plane_px;
+            __syncthreads();                                   // the previous cell's readers are done
+            for (int i = tid; i < HALF; i += 256) {
+                const int r = i / ITW, x = i - r * ITW;
+                const int gy = y0 - pad + r, gx = x0 - pad + x;
+                uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
+                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                    const size_t o = (size_t)gy * W + gx;
+                    h = src[o];
+                    l = src[o + lo_off];
+                }
+                const f32x2 v0 = join2(h.x, l.x), v1 = join2(h.y, l.y), v2 = join2(h.z, l.z), v3 = join2(h.w, l.w);
+                lds[i] = make_float4(v0[0], v0[1], v1[0], v1[1]);
+                lds[HALF + i] = make_float4(v2[0], v2[1], v3[0], v3[1]);
+            }
+            __syncthreads();
+            const float* wc = wt + ((size_t)kz * cells + c) * (K * K * 8);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                f32x2 px[IR][4];
+#pragma unroll
+                for (int i = 0; i < IR; ++i) {
+                    const int slot = (wave * R + i) * ITW + lane + kx;
+                    const float4 a = lds[slot], b = lds[HALF + slot];
+                    px[i][0] = (f32x2){a.x, a.y}; px[i][1] = (f32x2){a.z, a.w};
+                    px[i][2] = (f32x2){b.x, b.y}; px[i][3] = (f32x2){b.z, b.w};
+                }
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const float* w8 = wc + (kx * K + ky) * 8;          // wave-uniform: scalar loads
+                    const f32x2 w0 = {w8[0], w8[1]}, w1 = {w8[2], w8[3]}, w2 = {w8[4], w8[5]}, w3 = {w8[6], w8[7]};
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r] = __builtin_elementwise_fma(w0, px[r + ky][0], acc[r]);
+                        acc[r] = __builtin_elementwise_fma(w1, px[r + ky][1], acc[r]);
+                        acc[r] = __builtin_elementwise_fma(w2, px[r + ky][2], acc[r]);
+                        acc[r] = __builtin_elementwise_fma(w3, px[r + ky][3], acc[r]);
+                    }
+                }
+            }
+        }
+    }
+    float sc = 1.f, sh = 0.f;
+    if (nrm && norm_out) { sc = nrm[2]; sh = nrm[3]; }
+    const int ox = x0 + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int oy = y0 + wave * R + r;
+        if (oy < wy1 && ox < wx1) {
+            const size_t o = ((size_t)z * H + oy) * W + ox;
+            float v = acc[r][0] + acc[r][1];
+            if (res) v += res[o];
+            out[o] = (v + bias) * sc + sh;
+        }
+    }
+}
+
+// in: split cells [2][cells][D][H][W]; wt: [KZ][cells][K(kx)][K(ky)][8] fp32; out / res: fp32 [D][H][W]; the launch covers the
+// planes [z0, z1) x rows [y0, y1) x columns [x0, x1) of the output (pad = K / 2: same-size convolution)
+hipError_t launch_conv_cout1_split(const void* in, const float* wt, float* out, const float* res, const float* nrm, int norm_out,
+                                   float bias, int cells, int K, int KZ, int D, int H, int W, int z0, int z1, int y0, int y1,
+                                   int x0, int x1, hipStream_t s) {
+    if (z1 <= z0 || y1 <= y0 || x1 <= x0) return hipSuccess;
+    constexpr int TH = 32;
+    const int tiles_x = (x1 - x0 + 63) / 64, tiles_y = (y1 - y0 + TH - 1) / TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(z1 - z0), 1);
+    const int pad = K / 2;
+    if (K == 5) {
+        constexpr int LDSB = 2 * (TH + 4) * (64 + 4) * 16;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_split_kernel<5, TH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv_cout1_split_kernel<5, TH>), grid, dim3(256), LDSB, s, (const uint4*)in, wt, out, res, nrm, norm_out,
+                           bias, cells, KZ, D, H, W, pad, z0, y0, x0, y1, x1, tiles_x, tiles_y);
+    } else if (K == 3) {
+        constexpr int LDSB = 2 * (TH + 2) * (64 + 2) * 16;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_split_kernel<3, TH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL((conv_cout1_split_kernel<3, TH>), grid, dim3(256), LDSB, s, (const uint4*)in, wt, out, res, nrm, norm_out,
+                           bias, cells, KZ, D, H, W, pad, z0, y0, x0, y1, x1, tiles_x, tiles_y);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

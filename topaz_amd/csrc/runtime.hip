@@ -229,12 +229,26 @@ static void* pool_alloc(tpz_ctx* ctx, size_t bytes) {
     // round up so slightly larger requests can reuse the buffer
     size_t rounded = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
     if (hipMalloc(&p, rounded) != hipSuccess) {
-        // drop unused cached buffers and retry once
-        for (auto it = pool.begin(); it != pool.end();) {
-            if (!it->used) { (void)hipFree(it->p); it = pool.erase(it); }
-            else ++it;
+        // drop unused cached buffers and retry: first this pool's, then those of EVERY pool of the ctx (the pools of a batched
+        // pass -- up to lanes x 8 of them --, the lane pools, the ctx pool: a pass with other tile shapes, or a large frame on
+        // the ctx stream after a batched pass filled the device, finds its memory cached elsewhere)
+        auto trim = [](std::vector<tpz_ctx::Buf>& pl) {
+            for (auto it = pl.begin(); it != pl.end();) {
+                if (!it->used) { (void)hipFree(it->p); it = pl.erase(it); }
+                else ++it;
+            }
+        };
+        (void)hipGetLastError();
+        trim(pool);
+        if (hipMalloc(&p, rounded) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();          // (buffers released by passes still in flight on the lanes)
+            trim(ctx->pool);
+            for (auto& ln : ctx->lanes) trim(ln.pool);
+            for (auto& lane_pools : ctx->rec_pools)
+                for (auto& pl : lane_pools) trim(pl);
+            if (hipMalloc(&p, rounded) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
-        if (hipMalloc(&p, rounded) != hipSuccess) return nullptr;
     }
     pool.push_back({p, rounded, true});
     return p;
@@ -426,7 +440,9 @@ static int rec_flush(tpz_ctx* ctx) {
             if (cur[i] >= ctx->rec[i].size()) continue;
             const RecOp& o = ctx->rec[i][cur[i]];
             if (o.ks != o0.ks || o.a.plan != o0.a.plan || split_mode_of(o.a) != split_mode_of(o0.a)) continue;
-            if (i != lead && !o0.ks->launch_multi) continue;
+            // only what conv_split_multi_kernel is instantiated for merges (modes 0 / 1 / 2 / 11): a plane-stacked two-source
+            // launch whose chunks mix both tensors (MODE 3: odd widths of a user-trained 3-D U-Net, TPZ_NO_SRCMAJOR) goes alone
+            if (i != lead && (!o0.ks->launch_multi || split_mode_of(o0.a) == 3)) continue;
             list[m] = &o.a; who[m++] = i;
             flops += o.flops; bytes += o.bytes;
         }
@@ -481,6 +497,8 @@ struct LayerRT {
     // image (kx taps as input channels), a 1-output-channel conv as k virtual output channels + a shifted sum
     const SplitKernelInfo* ks_stem = nullptr;
     const SplitKernelInfo* ks_last = nullptr;
+    float* d_wlast = nullptr;                  // ... or (k = 3 / 5, few input channels) the vector-ALU stencil conv_cout1_split_kernel:
+                                               // its weights [kz][cell][kx][ky][8] fp32
     const SplitKernelInfo* ks_pool = nullptr;  // twin of ks / ks_stem with the following 2x2 max-pool fused (EPI_POOL)
     // ResidA blocks that change width, y = [bn1](conv1(t) + proj(h)) (resnet.py:185-202): on the 2xf16 path the 1x1 projection is
     // FOLDED into conv1's K loop (SplitArgs::fold_cells) -- the projection layer is then skipped (folded_into = index of conv1)
@@ -538,6 +556,7 @@ struct tpz_model {
     int n_conv = 0, n_conv_split = 0;     // convolution layers; those with a 2xf16 kernel (prepare_split)
     std::string off_path;                 // ... the others, "#layer KxK dD cin->cout, ..."
     bool split_ok = false;                // at least one layer has a 2xf16 kernel: the program runs in split mode
+    bool widened = false;                 // the program was loaded with its widths zero-padded to multiples of 16 (widen_program)
     long long n_split = 0, n_fallback = 0;
 };
 
@@ -985,7 +1004,7 @@ static int prepare_split_phases(tpz_ctx* ctx, tpz_model* m, const float* w, Laye
         if (!sp.low_with_skip) sub_w.insert(sub_w.end(), eff.begin(), eff.end());          // [parity][cout][c1][taps1]
         // 3-D with the skip cell: source-major cell order whenever the first source's planes fill whole chunks (then no chunk of
         // the K loop mixes the two tensors: conv_split.h MODE 11)
-        static const bool no_srcmajor = getenv("TPZ_NO_SRCMAJOR") != nullptr;   // A/B switch
+        const bool no_srcmajor = getenv("TPZ_NO_SRCMAJOR") != nullptr;   // A/B switch, read when the model is loaded
         sp.srcmajor = dims == 3 && sp.low_with_skip && !no_srcmajor && (k1z_n * (c1 / 8)) % sp.ks_low_plain->CC == 0;
         if (upload_split_weights(ctx, m, sp.low_with_skip ? *sp.ks_low_plain : *sp.ks_low, eff.data(), L.cout, c1e,
                                  &sp.n_cog_low, &sp.n_chunks_low, nullptr, nullptr, k1z_n, sp.srcmajor ? c1 : 0)) return 1;
@@ -1131,8 +1150,22 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
         }
         if (rt.ks_last) {
             const int k = L.k, kz_n = L.dims == 3 ? k : 1;
-            std::vector<float> w2((size_t)k * L.cin * kz_n * k);
             const float* w = blob + L.w_off;                         // [1][cin][kz][ky][kx]
+            // k = 3 / 5 over <= 1024 taps x channels (Conv(32, 1, 5), Conv3d(32, 1, 3)): the fp32 stencil on the vector ALUs
+            // (kernels_misc.hip conv_cout1_split_kernel) instead of a 16-row MFMA tile with one useful row per kx tap
+            static const bool no_valu_last = getenv("TPZ_NO_VALU_LAST") != nullptr;       // A/B switch
+            if (!no_valu_last && (k == 3 || k == 5) && (size_t)L.cin * k * k * kz_n <= 1024) {
+                const int cells = (int)split_cells(L.cin);
+                std::vector<float> wl((size_t)kz_n * cells * k * k * 8, 0.f);
+                for (int ci = 0; ci < L.cin; ++ci)
+                    for (int kz = 0; kz < kz_n; ++kz)
+                        for (int ky = 0; ky < k; ++ky)
+                            for (int kx = 0; kx < k; ++kx)
+                                wl[((((size_t)kz * cells + ci / 8) * k + kx) * k + ky) * 8 + ci % 8] =
+                                    w[(((size_t)ci * kz_n + kz) * k + ky) * k + kx];
+                if (upload(ctx, m, wl.data(), wl.size(), &rt.d_wlast)) return 1;
+            }
+            std::vector<float> w2((size_t)k * L.cin * kz_n * k);
             for (int v = 0; v < k; ++v)
                 for (int ci = 0; ci < L.cin; ++ci)
                     for (int kz = 0; kz < kz_n; ++kz)
@@ -1733,6 +1766,31 @@ static int run_stem_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot&
 static int run_last_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, Slot& dst, const float* d_nrm, int norm_out,
                           const Slot* sres = nullptr) {
     const tpz_layer& L = rt.L;
+    if (rt.d_wlast) {
+        // one pass: stencil + bias + residual + un-normalisation (conv_cout1_split_kernel)
+        const Rect& w = dst.need;
+        const int z0 = w.on ? w.z0 : 0, z1 = w.on ? std::min(dst.D, w.z1) : dst.D;
+        const int y0 = w.on ? w.y0 : 0, y1 = w.on ? std::min(dst.H, w.y1) : dst.H;
+        const int x0 = w.on ? w.x0 : 0, x1 = w.on ? std::min(dst.W, w.x1) : dst.W;
+        const double vox = (double)(z1 - z0) * (y1 - y0) * (x1 - x0);
+        const double taps = std::pow((double)L.k, L.dims);
+        const double fl = 2.0 * L.cin * taps * vox;
+        // algorithmic bytes: the input box (with its halo) once, the output (and the residual) once, the weights once
+        const double by = 32.0 * split_cells(s1.C) * (double)std::min(dst.D, z1 - z0 + (L.dims == 3 ? 2 * L.pad : 0)) *
+                              std::min(dst.H, y1 - y0 + 2 * L.pad) * std::min(dst.W, x1 - x0 + 2 * L.pad) +
+                          4.0 * vox * (sres ? 2 : 1) + 4.0 * L.cin * taps;
+        const void* ip = s1.p; const float* wp_ = rt.d_wlast; float* op = dst.p;
+        const float* resp = sres ? sres->p : nullptr;
+        const float b0 = L.b_off >= 0 ? rt.bias0 : 0.f;
+        const int cells = (int)split_cells(s1.C), k = L.k, kz = L.dims == 3 ? L.k : 1, Dd = dst.D, Hd = dst.H, Wd = dst.W;
+        hipError_t e = enqueue(ctx, 0, fl, "conv_cout1_split_kernel (last conv: fp32 stencil on the vector ALUs + bias + un-normalisation)",
+                               by, [=](hipStream_t st) {
+                                   return launch_conv_cout1_split(ip, wp_, op, resp, d_nrm, norm_out, b0, cells, k, kz, Dd, Hd, Wd, z0, z1,
+                                                                  y0, y1, x0, x1, st);
+                               });
+        if (e != hipSuccess) return fail(ctx, "conv_cout1_split failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     const SplitKernelInfo& ks = *rt.ks_last;
     const int Wp = dst.W + 2 * L.pad;
     const size_t rows = (size_t)dst.D * dst.H;
@@ -2296,9 +2354,94 @@ static int build_bias_arena(tpz_ctx* ctx, tpz_model* m) {
     return 0;
 }
 
+// The 2xf16 kernels address channels in 8-channel cells and walk their K loop in chunks of CC = 2 cells; a two-source layer
+// (fused upsample + concat, denoising/models.py:140-171) needs its first source to fill whole chunks.  A user-trained width
+// that is not a multiple of 16 (`UDenoiseNet2(nf=12)`: 24 -> 24 over sources of 12 + 12, 25 -> 64 over 24 + 1) therefore fell
+// to the fp32-MFMA kernels, 3 - 5x slower.  widen_program rewrites such a program with every intermediate tensor ZERO-PADDED to
+// the next multiple of 16 channels: padded output channels get zero weights / bias / affine / head weights (they come out as
+// exactly 0 through any activation with f(0) = 0), padded input channels zero weight columns, the channels of a second
+// source move up behind the padded first one.  Every real product and every real sum stays what it was (zeros added in
+// fp32): same arithmetic on the same values.  The 1-channel input, 1-output-channel convs, the fused head's single channel
+// and the network's last layer keep their widths.  Returns false when nothing needs padding.
+static bool widen_program(const tpz_layer* layers, int n_layers, const float* blob, size_t n_floats, std::vector<tpz_layer>& out_l,
+                          std::vector<float>& out_b) {
+    int max_slot = 0;
+    for (int i = 0; i < n_layers; ++i)
+        max_slot = std::max(max_slot, std::max(std::max(layers[i].src, layers[i].src2), std::max(layers[i].dst, layers[i].res)));
+    std::vector<int> chan(max_slot + 1, 0), pch(max_slot + 1, 0);
+    chan[0] = pch[0] = 1;
+    auto pad16 = [](int c) { return c <= 1 ? c : (c + 15) / 16 * 16; };
+    bool any = false;
+    out_l.assign(layers, layers + n_layers);
+    out_b.assign(blob, blob + n_floats);
+    for (int i = 0; i < n_layers; ++i) {
+        tpz_layer& L = out_l[i];
+        if (L.src < 0 || L.src > max_slot || L.dst <= 0) return false;              // (model_load reports the bad program)
+        const int c1 = chan[L.src], c2 = L.src2 >= 0 ? chan[L.src2] : 0;
+        const int p1 = pch[L.src], p2 = L.src2 >= 0 ? pch[L.src2] : 0;
+        if (L.op != TPZ_OP_CONV) { chan[L.dst] = c1; pch[L.dst] = p1; continue; }
+        if (L.cin != c1 + c2 || L.w_off < 0) return false;
+        const size_t taps = L.dims == 3 ? (size_t)L.k * L.k * L.k : (size_t)L.k * L.k;
+        if ((size_t)L.w_off + (size_t)L.cout * L.cin * taps > n_floats) return false;
+        const bool last = i == n_layers - 1;
+        const int pco = (last || L.cout == 1) ? L.cout : pad16(L.cout);
+        chan[L.dst] = L.head ? 1 : L.cout;
+        pch[L.dst] = L.head ? 1 : pco;
+        if (pco == L.cout && p1 == c1 && p2 == c2) continue;
+        any = true;
+        const int pci = p1 + p2;
+        const size_t w_new = out_b.size();
+        out_b.resize(w_new + (size_t)pco * pci * taps, 0.f);
+        for (int co = 0; co < L.cout; ++co) {
+            memcpy(&out_b[w_new + ((size_t)co * pci) * taps], blob + L.w_off + ((size_t)co * L.cin) * taps, (size_t)c1 * taps * sizeof(float));
+            if (c2 > 0)
+                memcpy(&out_b[w_new + ((size_t)co * pci + p1) * taps], blob + L.w_off + ((size_t)co * L.cin + c1) * taps,
+                       (size_t)c2 * taps * sizeof(float));
+        }
+        auto widen_vec = [&](int64_t& off) {
+            if (off < 0 || pco == L.cout) return;
+            const size_t o = out_b.size();
+            out_b.resize(o + pco, 0.f);
+            memcpy(&out_b[o], blob + off, (size_t)L.cout * sizeof(float));
+            off = (int64_t)o;
+        };
+        widen_vec(L.b_off); widen_vec(L.post_scale_off); widen_vec(L.post_shift_off);
+        if (L.head) widen_vec(L.head_w_off);
+        L.w_off = (int64_t)w_new;
+        L.cin = pci;
+        L.cout = pco;
+    }
+    return any;
+}
+
+static int model_load_one(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
+                          const std::vector<int>& preset_chan, tpz_model** out);
+
 // preset_chan: channels of the externally provided slots (slot 0, and tpz_conv's extra sources)
 static int model_load(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
                       const std::vector<int>& preset_chan, tpz_model** out) {
+    if (model_load_one(ctx, layers, n_layers, h_blob, n_floats, preset_chan, out)) return 1;
+    tpz_model* m = *out;
+    static const bool no_widen = getenv("TPZ_NO_WIDEN") != nullptr;         // A/B switch
+    if (preset_chan.size() != 1 || no_widen || ctx->exact || m->n_conv_split == m->n_conv) return 0;
+    // some layer has no 2xf16 kernel at the widths as given: try the zero-padded program, keep whichever covers more layers
+    std::vector<tpz_layer> wl;
+    std::vector<float> wb;
+    if (!widen_program(layers, n_layers, h_blob, n_floats, wl, wb)) return 0;
+    tpz_model* mw = nullptr;
+    if (model_load_one(ctx, wl.data(), n_layers, wb.data(), wb.size(), preset_chan, &mw)) return 0;    // (keep the plain one)
+    if (mw->n_conv - mw->n_conv_split < m->n_conv - m->n_conv_split) {
+        mw->widened = true;
+        tpz_model_free(m);
+        *out = mw;
+    } else {
+        tpz_model_free(mw);
+    }
+    return 0;
+}
+
+static int model_load_one(tpz_ctx* ctx, const tpz_layer* layers, int n_layers, const float* h_blob, size_t n_floats,
+                          const std::vector<int>& preset_chan, tpz_model** out) {
     if (!ctx || !layers || !out || n_layers < 1) return fail(ctx, "tpz_model_load: bad arguments");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -3016,6 +3159,16 @@ int tpz_affine(tpz_ctx* ctx, const float* d_x, size_t n, float scale, float shif
     HIPCHK(ctx, hipSetDevice(ctx->device));
     prof_begin(ctx, 2, 0);
     hipError_t e = launch_affine(d_x, d_y, n, scale, shift, ctx->stream);
+    prof_end(ctx);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+int tpz_normalize(tpz_ctx* ctx, const float* d_x, size_t n, float mean, float std, float* d_y) {
+    if (!ctx || !d_x || !d_y) return fail(ctx, "tpz_normalize: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    prof_begin(ctx, 2, 0);
+    hipError_t e = launch_normalize(d_x, d_y, n, mean, std, ctx->stream);
     prof_end(ctx);
     HIPCHK(ctx, e);
     return 0;

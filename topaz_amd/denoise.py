@@ -104,7 +104,10 @@ class Denoise3D(Denoise):
         if across_ranks and patch_size >= 1:
             from . import parallel
             rank, _, world = parallel.init_from_env()
-            y = parallel.sum_to_root(dm.denoise_3d(x, patch_size, padding, shard=rank, n_shards=world))
+            part = dm.denoise_3d(x, patch_size, padding, shard=rank, n_shards=world)
+            if parallel.collective_device(0).type == 'cpu':       # gloo rehearsal (ranks sharing a GPU): reduce host tensors
+                part = part.cpu()
+            y = parallel.sum_to_root(part)
             if y is None:
                 return None
         else:
@@ -153,7 +156,7 @@ def denoise_image_device(x: torch.Tensor, models: List[Denoise], patch_size: int
     work of the network)."""
     from . import runtime as rt
     mu, std = rt.mean_std(x, unbiased=False)
-    xn = rt.affine(x, 1.0 / std, -mu / std)
+    xn = rt.normalize(x, mu, std)              # (x - mu) / std as numpy rounds it; std == 0 -> inf / nan like upstream
     out = None
     for model in models:
         y = model.denoise_device(xn, patch_size, padding)
@@ -162,7 +165,7 @@ def denoise_image_device(x: torch.Tensor, models: List[Denoise], patch_size: int
         out = out / len(models)
     if normalize:
         m2, s2 = rt.mean_std(out, unbiased=False)
-        return rt.affine(out, 1.0 / s2, -m2 / s2)
+        return rt.normalize(out, m2, s2)
     return rt.affine(out, std, mu)
 
 

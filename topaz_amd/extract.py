@@ -386,7 +386,7 @@ class PickSink:
             return
         tables = {i: (name, s, c) for i, name, s, c in self.rows}
         if world > 1:
-            dev = torch.device('cuda', local_rank)
+            dev = parallel.collective_device(local_rank)
             got = parallel.gather_pick_tables([r[0] for r in self.rows],
                                               [torch.from_numpy(np.asarray(r[2], dtype=np.float32)) for r in self.rows],
                                               [torch.from_numpy(np.asarray(r[3], dtype=np.int32)) for r in self.rows], dev)
@@ -417,12 +417,13 @@ def extract_particles(paths: List[str], model, device: int, batch_size: int, thr
     report('Beginning extraction')
     rank, local_rank, world = parallel.init_from_env()
     if world > 1:
-        device = local_rank
+        device = parallel.rank_device(local_rank)
     if len(paths):
         paths = list(paths)
-    elif os.environ.get('TOPAZ_AMD_INPUT_LIST'):
-        # a rank of `topaz extract --gpus N < list`: the launcher read stdin once for all ranks (main.py)
-        with open(os.environ['TOPAZ_AMD_INPUT_LIST']) as f:
+    elif parallel.under_launcher() and os.environ.get('TOPAZ_AMD_INPUT_LIST'):
+        # a rank of `topaz extract --gpus N < list`: the launcher read stdin once for all ranks (main.py).  Only a rank process
+        # honours the variable, and only once: a stale / exported copy must not silently replace stdin elsewhere
+        with open(os.environ.pop('TOPAZ_AMD_INPUT_LIST')) as f:
             paths = list(stream_inputs(f))
     else:
         paths = list(stream_inputs(sys.stdin))

@@ -47,7 +47,10 @@ def main(argv=None):
             if listfile:
                 import os
                 os.unlink(listfile)
-    return args.func(args)
+    # like topaz/main.py:148 the command's return value (denoise returns its output paths) is NOT the exit status:
+    # `raise SystemExit(<list>)` would print the list and exit 1 after a successful run
+    args.func(args)
+    return 0
 
 
 def _ranks_to_launch(args) -> int:

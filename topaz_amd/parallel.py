@@ -25,7 +25,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('TOPAZ_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             if world > 1:
                 preflight(rank, local_rank, world)        # one line per rank on stderr; fails fast on a rank without a GPU
@@ -34,6 +34,22 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def rank_device(local_rank: int) -> int:
+    """HIP device of a rank process: its local rank -- or, with TOPAZ_AMD_SHARE_GPU=1 (a rehearsal of the multi-rank job on a
+    box with fewer GPUs than ranks: RCCL refuses two ranks on one device, so this goes with TOPAZ_AMD_DIST_BACKEND=gloo),
+    local_rank modulo the visible devices."""
+    if os.environ.get('TOPAZ_AMD_SHARE_GPU') == '1' and torch.cuda.is_available():
+        return local_rank % max(1, torch.cuda.device_count())
+    return local_rank
+
+
+def collective_device(local_rank: int) -> torch.device:
+    """where the tensors of the exchange step live: the rank's GPU under RCCL, host memory under gloo"""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'gloo':
+        return torch.device('cpu')
+    return torch.device('cuda', rank_device(local_rank))
 
 
 def preflight(rank: int, local_rank: int, world: int, stream=None) -> dict:
@@ -187,14 +203,20 @@ def _set_affinity_all_threads(cpus: Sequence[int]) -> None:
         pass
 
 
+_PINNED: Optional[List[int]] = None
+
+
 def pin_this_rank(local_rank: int, local_world: int) -> Optional[List[int]]:
     """Host placement of this rank process, applied by the rank itself (never in a fork hook of the launcher): the CPU set
     launch_local_ranks handed over in TOPAZ_AMD_RANK_CPUS, else -- torchrun, or a *_VISIBLE_DEVICES subset the launcher would
     not guess about -- the CPUs next to ITS GPU, resolved through HIP's own PCI address of the device (gpu_numa_nodes), else the
     DRM card order when every GPU is visible.  Every existing thread is moved.  No-op with TOPAZ_AMD_NO_AFFINITY=1 or where
     affinity cannot be set; a failure leaves the rank unpinned rather than failing the job."""
+    global _PINNED
     if os.environ.get('TOPAZ_AMD_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
         return None
+    if _PINNED is not None:                   # init_from_env is called by every layer that shards (command, stream, sink): pin once
+        return list(_PINNED)
     try:
         given = os.environ.get('TOPAZ_AMD_RANK_CPUS')
         if given:
@@ -207,6 +229,7 @@ def pin_this_rank(local_rank: int, local_world: int) -> Optional[List[int]]:
             return None
         _set_affinity_all_threads(cpus)
         os.environ['TOPAZ_AMD_RANK_CPUS'] = ','.join(map(str, cpus))
+        _PINNED = list(cpus)
         return list(cpus)
     except (OSError, ValueError):
         return None

@@ -580,6 +580,16 @@ def affine(x: torch.Tensor, scale: float, shift: float, ctx: Optional[Context] =
     return y
 
 
+def normalize(x: torch.Tensor, mean: float, std: float, ctx: Optional[Context] = None) -> torch.Tensor:
+    """(x - mean) / std as numpy evaluates it in fp32 (tpz_normalize): subtraction first, IEEE division; std == 0 -> inf / nan"""
+    ctx = ctx or get_context()
+    ctx.bind_current_stream()
+    x = as_device_f32(x, ctx)
+    y = torch.empty_like(x)
+    check(ctx.lib.tpz_normalize(ctx.handle, _ptr(x), x.numel(), float(mean), float(std), _ptr(y)), ctx.handle)
+    return y
+
+
 def filter_2d(x: torch.Tensor, w, bias: float = 0.0, ctx: Optional[Context] = None) -> torch.Tensor:
     ctx = ctx or get_context()
     ctx.bind_current_stream()
