@@ -312,6 +312,14 @@ int tpz_prof_get_kernel_bytes(tpz_ctx* ctx, int rank, double* bytes);
  * is quoted at: bench.py reports the dominant kernel against both. */
 int tpz_prof_mfma_sustained(tpz_ctx* ctx, int ms, int zero_operands, double* tflops, double* clock_ratio);
 
+/* ---- pick-table text (host only) ------------------------------------------------------------------------------------
+ * replaces the per-pick f-string of topaz/extract.py:341-354: n rows `image_name \t x \t y [\t z] \t score \n` into `out`
+ * (capacity `cap` bytes; strlen(image_name) + 80 per row is always enough).  coords: int32, `coord_stride` ints per row of
+ * which the first `dims` are written; a float32 score prints as Python prints float(score): the shortest digits that
+ * round-trip the float64 value (repr).  Returns the bytes written, -1 on bad arguments, -2 when `out` is too small. */
+long long tpz_format_picks(const char* image_name, const int32_t* coords, int coord_stride, int dims, const float* scores,
+                           long long n, char* out, long long cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -279,3 +279,27 @@ def test_particle_pixel_count_keeps_the_reference_cube_quirk():
     for (r, d), n in want.items():
         assert pixels_given_radius(r, dims=d) == n, (r, d)
     assert abs(calculate_pi(300, 14, 4096 * 4096) - 17777 * 300 / 4096 ** 2) < 1e-12
+
+
+def test_pick_rows_are_the_reference_f_string_byte_for_byte():
+    """tpz_format_picks (host code of the library, csrc/host_io.hip) writes the rows of `topaz extract`'s pick table
+    (topaz/extract.py:341-354: f'{name}\\t{x}\\t{y}\\t{score}' with numpy scalars -- a float32 score prints with the digits of
+    its float64 value, CPython's repr: shortest round-trip digits, fixed notation for 1e-4 <= |v| < 1e16, '.0' on integers,
+    two-digit exponents) -- random scores, every notation boundary, signed zero, subnormals, inf / nan; 2-D and 3-D rows,
+    int64 coordinates as np.round(coords * scale).astype(int) hands them over."""
+    from topaz_amd.utils.files import format_pick_rows
+    rs = np.random.RandomState(3)
+    n = 20000
+    coords = rs.randint(0, 11520, size=(n, 2)).astype(np.int32)
+    scores = (rs.randn(n) * 6 - 3).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-4, 9.9e-5, 1e-5, 123456.0, 1e15, 1e16, 1.5e16, 1e17, 3.4e38, 1e-38, 1e-45,
+                        np.inf, -np.inf, np.nan, 0.1, 100.0, 16777216.0, 0.5, 2.5e-5, -7e-10, 1e22, 9999999.0, 0.001, -0.06772084],
+                       dtype=np.float32)
+    scores[:len(special)] = special
+    scores[len(special):2 * len(special)] = -special
+    ref = ''.join('\t'.join(['mic_a'] + [format(v, '') for v in row] + [format(s, '')]) + '\n' for row, s in zip(coords, scores))
+    assert format_pick_rows('mic_a', coords, scores, 2) == ref.encode()
+    c3 = rs.randint(0, 512, size=(300, 3)).astype(np.int64)
+    ref3 = ''.join(f'tomo\t{r[0]}\t{r[1]}\t{r[2]}\t{s}\n' for r, s in zip(c3, scores[:300]))
+    assert format_pick_rows('tomo', c3, scores[:300], 3) == ref3.encode()
+    assert format_pick_rows('x', np.zeros((0, 2), dtype=np.int32), np.zeros(0, dtype=np.float32)) == b''

@@ -45,6 +45,23 @@ __global__ void k(const float* v, const unsigned* h, float* out, int n) {
     out[6 * i + 4] = mix_sub<0>(v[i], h[i]) - (v[i] - (float)hh[0]);
     out[6 * i + 5] = mix_sub<1>(v[i], h[i]) - (v[i] - (float)hh[1]);
 }
+__device__ __forceinline__ f32x2 join2m(unsigned hi, unsigned lo) {      // split_fmt.h: hi * 1.0 + lo, both read as f16 halves
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(d0) : "v"(hi), "v"(lo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d1) : "v"(hi), "v"(lo));
+    return (f32x2){d0, d1};
+}
+__global__ void k3(const unsigned* h, unsigned* bad, int n) {      // join of (hi, lo) pairs: one mixed FMA vs two conversions + add
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const unsigned hi = h[i], lo = (h[i + 1] & 0x83ff83ffu) | 0x10001000u;      // lo halves ~2^-11 of the hi halves' range, some subnormal-ish
+    const f32x2 a = join2m(hi, lo);
+    const f32x2 b = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2) + __builtin_convertvector(__builtin_bit_cast(f16x2, lo), f32x2);
+    const f32x2 c = join2m(hi, h[i + 1] & 0x03ff03ffu);                         // subnormal lo halves
+    const f32x2 d = __builtin_convertvector(__builtin_bit_cast(f16x2, hi), f32x2) +
+                    __builtin_convertvector(__builtin_bit_cast(f16x2, h[i + 1] & 0x03ff03ffu), f32x2);
+    if (a[0] != b[0] || a[1] != b[1] || c[0] != d[0] || c[1] != d[1]) atomicAdd(bad, 1u);
+}
 int main() {
     const int n = 1 << 16;
     std::vector<float> v(n); std::vector<unsigned> h(n);
@@ -67,5 +84,10 @@ int main() {
     int bad2 = 0;
     for (int i = 0; i + 1 < n; ++i) if (o2[2 * i] != o2[2 * i + 1]) ++bad2;
     printf("v_fma_mixlo_f16 / mixhi_f16 split probe: %d of %d mismatches\n", bad2, n - 1);
-    return bad != 0 || bad2 != 0;
+    unsigned* d3; hipMalloc(&d3, 4); hipMemset(d3, 0, 4);
+    hipLaunchKernelGGL(k3, dim3(n / 256), dim3(256), 0, 0, dh, d3, n);
+    unsigned bad3 = 0;
+    hipMemcpy(&bad3, d3, 4, hipMemcpyDeviceToHost);
+    printf("v_fma_mix_f32 join (two f16 operands) probe: %u of %d mismatches\n", bad3, n - 1);
+    return bad != 0 || bad2 != 0 || bad3 != 0;
 }

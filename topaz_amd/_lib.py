@@ -54,6 +54,7 @@ _SIGNATURES = {
                               _P, _P, _P, _P]),
     'tpz_affine': (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
     'tpz_normalize': (C.c_int, [_P, _P, C.c_size_t, C.c_float, C.c_float, _P]),
+    'tpz_format_picks': (C.c_longlong, [C.c_char_p, _P, C.c_int, C.c_int, _P, C.c_longlong, _P, C.c_longlong]),
     'tpz_filter_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
     'tpz_nms_2d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     'tpz_nms_3d': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, _P, _P, C.c_int,

@@ -2,6 +2,7 @@
 // and 1->1 filters, 2x max-pool, mean/std reductions, affine maps, crop/paste and 3-D tiling.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "conv_mfma.h"
 #include "kernels_misc.h"
 #include "split_fmt.h"
@@ -777,67 +778,102 @@ hipError_t launch_shiftsum(const float* Y, float* out, int K, size_t rows, int W
 // un-normalisation of Denoise._denoise (denoise.py:291-294) are applied in the same pass: no k-plane scratch tensor, no
 // shift-sum launch.
 // ------------------------------------------------------------------------------------------
-template <int K, int TH>
+template <int K, int TH, int ZP>
 __global__ __launch_bounds__(256, 2) void conv_cout1_split_kernel(const uint4* __restrict__ in, const float* __restrict__ wt,
                                                                   float* __restrict__ out, const float* __restrict__ res,
                                                                   const float* __restrict__ nrm, int norm_out, float bias,
                                                                   int cells, int KZ, int D, int H, int W, int pad, int wz0,
-                                                                  int wy0, int wx0, int wy1, int wx1, int tiles_x, int tiles_y) {
+                                                                  int wz1, int wy0, int wx0, int wy1, int wx1, int tiles_x,
+                                                                  int tiles_y) {
     constexpr int TW = 64, R = TH / 4, IR = R + K - 1, ITH = TH + K - 1, ITW = TW + K - 1;
     constexpr int HALF = ITH * ITW;                 // 16-byte slots per half-cell plane of the LDS tile
+    constexpr int NJ = (HALF + 255) / 256;          // input pixels a thread stages per (plane, cell)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float4* const lds = reinterpret_cast<float4*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    const int z = wz0 + (int)blockIdx.y;
+    // the workgroup's ZP output planes z0 .. z0 + ZP - 1 (3-D: every staged input plane serves up to min(ZP, K) of them -- the
+    // planes of a k^3 stencil are re-read k times otherwise; 2-D: ZP = 1)
+    const int z0 = wz0 + (int)blockIdx.y * ZP;
     const int y0 = wy0 + by * TH, x0 = wx0 + bx * TW;
     const size_t plane_px = (size_t)H * W, cell_px = (size_t)D * plane_px;
     const size_t lo_off = (size_t)cells * cell_px;             // cells from a hi cell to its lo cell
-    f32x2 acc[R];
+    // the tile's input pixels this thread stages: their offsets within a plane (the same for every plane and cell); -1 outside
+    // the image and outside what the launch window's outputs read (a tile may overhang the window: those outputs are not stored)
+    int poff[NJ];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = (f32x2){0.f, 0.f};
-    for (int kz = 0; kz < KZ; ++kz) {
-        const int iz = z + kz - (KZ > 1 ? pad : 0);
-        if ((unsigned)iz >= (unsigned)D) continue;             // (zero padding in z: nothing to add; uniform per workgroup)
-        for (int c = 0; c < cells; ++c) {
-            // ---- stage: cell c of plane iz, rows y0 - pad .. , columns x0 - pad ..  -> fp32 in the LDS
-            const uint4* src = in + ((size_t)c * D + iz) * plane_px;
-            __syncthreads();                                   // the previous cell's readers are done
-            for (int i = tid; i < HALF; i += 256) {
-                const int r = i / ITW, x = i - r * ITW;
-                const int gy = y0 - pad + r, gx = x0 - pad + x;
-                uint4 h = make_uint4(0, 0, 0, 0), l = make_uint4(0, 0, 0, 0);
-                if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                    const size_t o = (size_t)gy * W + gx;
-                    h = src[o];
-                    l = src[o + lo_off];
-                }
-                const f32x2 v0 = join2(h.x, l.x), v1 = join2(h.y, l.y), v2 = join2(h.z, l.z), v3 = join2(h.w, l.w);
+    for (int j = 0; j < NJ; ++j) {
+        const int i = tid + j * 256;
+        const int r = i / ITW, x = i - r * ITW;
+        const int gy = y0 - pad + r, gx = x0 - pad + x;
+        const bool ok = i < HALF && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && gy < wy1 + pad && gx < wx1 + pad;
+        poff[j] = ok ? gy * W + gx : -1;
+    }
+    // stage s = pi * cells + c: cell c of input plane z0 + pi - pad_z.  Its pixels travel global -> registers (issued one stage
+    // AHEAD, in flight under the arithmetic of the current stage) -> joined to fp32 -> LDS.
+    const int pad_z = KZ > 1 ? pad : 0;
+    const int S = (ZP + KZ - 1) * cells;
+    uint4 gh[NJ], gl[NJ];
+    auto fetch = [&](int s) {
+        const int pi = s / cells, c = s - pi * cells, iz = z0 + pi - pad_z;
+        const bool plane_ok = (unsigned)iz < (unsigned)D && iz < wz1 + pad_z;     // (zero padding in z; planes past the window)
+        const uint4* src = in + ((size_t)c * D + (plane_ok ? iz : 0)) * plane_px;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gh[j] = make_uint4(0, 0, 0, 0);
+            gl[j] = make_uint4(0, 0, 0, 0);
+            if (plane_ok && poff[j] >= 0) {
+                gh[j] = src[poff[j]];
+                gl[j] = src[(size_t)poff[j] + lo_off];
+            }
+        }
+    };
+    f32x2 acc[ZP][R];
+#pragma unroll
+    for (int o = 0; o < ZP; ++o)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[o][r] = (f32x2){0.f, 0.f};
+    fetch(0);
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();                                       // the previous stage's readers are done
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int i = tid + j * 256;
+            if (i < HALF) {
+                const f32x2 v0 = join2m(gh[j].x, gl[j].x), v1 = join2m(gh[j].y, gl[j].y);
+                const f32x2 v2 = join2m(gh[j].z, gl[j].z), v3 = join2m(gh[j].w, gl[j].w);
                 lds[i] = make_float4(v0[0], v0[1], v1[0], v1[1]);
                 lds[HALF + i] = make_float4(v2[0], v2[1], v3[0], v3[1]);
             }
-            __syncthreads();
-            const float* wc = wt + ((size_t)kz * cells + c) * (K * K * 8);
+        }
+        __syncthreads();
+        if (s + 1 < S) fetch(s + 1);
+        const int pi = s / cells, c = s - pi * cells;
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                f32x2 px[IR][4];
+        for (int kx = 0; kx < K; ++kx) {
+            f32x2 px[IR][4];
 #pragma unroll
-                for (int i = 0; i < IR; ++i) {
-                    const int slot = (wave * R + i) * ITW + lane + kx;
-                    const float4 a = lds[slot], b = lds[HALF + slot];
-                    px[i][0] = (f32x2){a.x, a.y}; px[i][1] = (f32x2){a.z, a.w};
-                    px[i][2] = (f32x2){b.x, b.y}; px[i][3] = (f32x2){b.z, b.w};
-                }
+            for (int i = 0; i < IR; ++i) {
+                const int slot = (wave * R + i) * ITW + lane + kx;
+                const float4 a = lds[slot], b = lds[HALF + slot];
+                px[i][0] = (f32x2){a.x, a.y}; px[i][1] = (f32x2){a.z, a.w};
+                px[i][2] = (f32x2){b.x, b.y}; px[i][3] = (f32x2){b.z, b.w};
+            }
+#pragma unroll
+            for (int o = 0; o < ZP; ++o) {
+                const int kz = pi - o;                             // output plane z0 + o takes this input plane as its tap kz
+                if (kz < 0 || kz >= KZ) continue;                  // (wave-uniform)
+                const float* wc = wt + ((size_t)kz * cells + c) * (K * K * 8);
 #pragma unroll
                 for (int ky = 0; ky < K; ++ky) {
-                    const float* w8 = wc + (kx * K + ky) * 8;          // wave-uniform: scalar loads
+                    const float* w8 = wc + (kx * K + ky) * 8;      // wave-uniform: scalar loads
                     const f32x2 w0 = {w8[0], w8[1]}, w1 = {w8[2], w8[3]}, w2 = {w8[4], w8[5]}, w3 = {w8[6], w8[7]};
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        acc[r] = __builtin_elementwise_fma(w0, px[r + ky][0], acc[r]);
-                        acc[r] = __builtin_elementwise_fma(w1, px[r + ky][1], acc[r]);
-                        acc[r] = __builtin_elementwise_fma(w2, px[r + ky][2], acc[r]);
-                        acc[r] = __builtin_elementwise_fma(w3, px[r + ky][3], acc[r]);
+                        acc[o][r] = __builtin_elementwise_fma(w0, px[r + ky][0], acc[o][r]);
+                        acc[o][r] = __builtin_elementwise_fma(w1, px[r + ky][1], acc[o][r]);
+                        acc[o][r] = __builtin_elementwise_fma(w2, px[r + ky][2], acc[o][r]);
+                        acc[o][r] = __builtin_elementwise_fma(w3, px[r + ky][3], acc[o][r]);
                     }
                 }
             }
@@ -847,53 +883,60 @@ __global__ __launch_bounds__(256, 2) void conv_cout1_split_kernel(const uint4* _
     if (nrm && norm_out) { sc = nrm[2]; sh = nrm[3]; }
     const int ox = x0 + lane;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int oy = y0 + wave * R + r;
-        if (oy < wy1 && ox < wx1) {
-            const size_t o = ((size_t)z * H + oy) * W + ox;
-            float v = acc[r][0] + acc[r][1];
-            if (res) v += res[o];
-            out[o] = (v + bias) * sc + sh;
+    for (int o = 0; o < ZP; ++o) {
+        const int z = z0 + o;
+        if (z >= wz1) continue;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int oy = y0 + wave * R + r;
+            if (oy < wy1 && ox < wx1) {
+                const size_t idx = ((size_t)z * H + oy) * W + ox;
+                float v = acc[o][r][0] + acc[o][r][1];
+                if (res) v += res[idx];
+                out[idx] = (v + bias) * sc + sh;
+            }
         }
     }
 }
 
 // in: split cells [2][cells][D][H][W]; wt: [KZ][cells][K(kx)][K(ky)][8] fp32; out / res: fp32 [D][H][W]; the launch covers the
 // planes [z0, z1) x rows [y0, y1) x columns [x0, x1) of the output (pad = K / 2: same-size convolution)
+template <int K, int TH, int ZP>
+static hipError_t launch_cout1_cfg(const void* in, const float* wt, float* out, const float* res, const float* nrm, int norm_out,
+                                   float bias, int cells, int KZ, int D, int H, int W, int z0, int z1, int y0, int y1, int x0,
+                                   int x1, hipStream_t s) {
+    constexpr int LDSB = 2 * (TH + K - 1) * (64 + K - 1) * 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_split_kernel<K, TH, ZP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const int tiles_x = (x1 - x0 + 63) / 64, tiles_y = (y1 - y0 + TH - 1) / TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((z1 - z0 + ZP - 1) / ZP), 1);
+    hipLaunchKernelGGL((conv_cout1_split_kernel<K, TH, ZP>), grid, dim3(256), LDSB, s, (const uint4*)in, wt, out, res, nrm, norm_out,
+                       bias, cells, KZ, D, H, W, K / 2, z0, z1, y0, x0, y1, x1, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_cout1_split(const void* in, const float* wt, float* out, const float* res, const float* nrm, int norm_out,
                                    float bias, int cells, int K, int KZ, int D, int H, int W, int z0, int z1, int y0, int y1,
                                    int x0, int x1, hipStream_t s) {
     if (z1 <= z0 || y1 <= y0 || x1 <= x0) return hipSuccess;
-    constexpr int TH = 32;
-    const int tiles_x = (x1 - x0 + 63) / 64, tiles_y = (y1 - y0 + TH - 1) / TH;
-    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(z1 - z0), 1);
-    const int pad = K / 2;
-    if (K == 5) {
-        constexpr int LDSB = 2 * (TH + 4) * (64 + 4) * 16;
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_split_kernel<5, TH>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
-        hipLaunchKernelGGL((conv_cout1_split_kernel<5, TH>), grid, dim3(256), LDSB, s, (const uint4*)in, wt, out, res, nrm, norm_out,
-                           bias, cells, KZ, D, H, W, pad, z0, y0, x0, y1, x1, tiles_x, tiles_y);
-    } else if (K == 3) {
-        constexpr int LDSB = 2 * (TH + 2) * (64 + 2) * 16;
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_cout1_split_kernel<3, TH>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
-        hipLaunchKernelGGL((conv_cout1_split_kernel<3, TH>), grid, dim3(256), LDSB, s, (const uint4*)in, wt, out, res, nrm, norm_out,
-                           bias, cells, KZ, D, H, W, pad, z0, y0, x0, y1, x1, tiles_x, tiles_y);
-    } else {
-        return hipErrorInvalidValue;
+    if (KZ != 1 && KZ != K) return hipErrorInvalidValue;
+    // a pixel's sum is formed in the same order whatever ZP: the choice is free (2-D: one plane; 3-D: two output planes per
+    // workgroup share four staged input planes instead of six)
+    if (K == 5 && KZ == 1) return launch_cout1_cfg<5, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+    if (K == 3 && KZ == 1) return launch_cout1_cfg<3, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+    if (K == 3) {
+        static const int zp = getenv("TPZ_COUT1_ZP") ? atoi(getenv("TPZ_COUT1_ZP")) : 2;          // A/B switch
+        if (zp == 1) return launch_cout1_cfg<3, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+        if (zp == 4) return launch_cout1_cfg<3, 32, 4>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+        return launch_cout1_cfg<3, 32, 2>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
     }
-    return hipGetLastError();
+    if (K == 5) return launch_cout1_cfg<5, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+    return hipErrorInvalidValue;
 }
 
 // space-to-depth of a 1-channel image / volume into one split cell per low-resolution pixel: channel

@@ -62,6 +62,13 @@ __device__ __forceinline__ void split2m(f32x2 v, unsigned& hi, unsigned& lo) {
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(v[1]));
     lo = l;
 }
+// join2 with one v_fma_mix_f32 per value (both halves read as f16 operands: hi * 1.0 + lo): no conversions at all
+__device__ __forceinline__ f32x2 join2m(unsigned hi, unsigned lo) {
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(d0) : "v"(hi), "v"(lo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d1) : "v"(hi), "v"(lo));
+    return (f32x2){d0, d1};
+}
 // c + (float2)(the two f16 halves of h): two v_fma_mix_f32
 __device__ __forceinline__ f32x2 add_halves(f32x2 c, unsigned h) {
     float d0, d1;

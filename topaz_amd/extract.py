@@ -394,14 +394,14 @@ class PickSink:
                 tables = {i: (os.path.splitext(os.path.basename(paths[i]))[0], s.numpy(), c.numpy()) for i, (s, c) in got.items()}
         if rank != 0:
             return
+        # rows formatted by the library's host-side writer (tpz_format_picks: the f-string's text -- a float32 score with the
+        # digits of its float64 value -- byte for byte; tests/test_cpu_host.py), not by a Python loop over the picks
         out = sys.stdout if self.path is None else open(self.path, 'w')
         try:
             print('image_name\tx_coord\ty_coord' + ('\tz_coord' if self.dims == 3 else '') + '\tscore', file=out)
             for i in sorted(tables):
                 name, scores, coords = tables[i]
-                for row, s in zip(coords, scores):
-                    # (format(), not str(): the reference's f-string prints a float32 score with float64 digits)
-                    out.write('\t'.join([name] + [format(v, '') for v in row[:self.dims]] + [format(s, '')]) + '\n')
+                out.write(file_utils.format_pick_rows(name, coords, scores, self.dims).decode())
         finally:
             if out is not sys.stdout:
                 out.close()
