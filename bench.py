@@ -696,10 +696,14 @@ def main():
         # the suppression's host read of the pick count, so the host clock is the step's clock) and the device memory in use
         # after the first steps / at the end -- the workspace pools must not grow once they are warm
         picks = []
+        marks = {min(args.steps, 8) - 1, args.steps // 4, args.steps // 2, args.steps - 1}
         for i in range(args.steps):
-            picks.append(run_step(models, imgs[i % n_res], args))
+            sc_i, co_i = run_step(models, imgs[i % n_res], args)
+            # the pick table leaves the device at once, as in `topaz extract` (PickSink.add takes host arrays): what is kept for
+            # the final gather is its n rows, not the capacity-sized device buffers the suppression wrote them into
+            picks.append((sc_i.cpu(), co_i.cpu() if co_i is not None else None))
             step_t.append(time.perf_counter())
-            if i in (min(args.steps, 8) - 1, args.steps - 1):
+            if i in marks:
                 free_b, total_b = torch.cuda.mem_get_info(dev)
                 mem_used[i] = total_b - free_b
     else:
@@ -969,7 +973,7 @@ def main():
                 'images': n, 'first_ms_per_step': sum(d_ms[:w]) / w, 'last_ms_per_step': sum(d_ms[-w:]) / w, 'window': w,
                 'slowest_step_ms': max(d_ms), 'fastest_step_ms': min(d_ms),
                 'device_bytes_in_use_after_step': {str(k + 1): int(mem_used[k]) for k in ks},
-                'pool_growth_bytes_after_warm_up': int(mem_used[ks[-1]] - mem_used[ks[0]]) if len(ks) == 2 else 0,
+                'pool_growth_bytes_after_warm_up': int(mem_used[ks[-1]] - mem_used[ks[0]]) if len(ks) >= 2 else 0,
                 'peak_device_gb': max(mem_used.values()) / 1e9 if mem_used else None,
                 'fp32_reruns': fp32_reruns,
                 'what': f'--scaling strong: the fixed job of {args.images} micrographs ({n} on this rank, cycling through '

@@ -255,8 +255,8 @@ long long tpz_prof_launches(tpz_ctx* ctx);
  * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
  * (TPZ_NO_ROI=1 in the environment or on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones.
  * The tiles of tpz_denoise_3d (denoise.py:340-377: patch^3 voxels kept of a (patch + 2*padding)^3 tile, 1/8 at the CLI's 96 / 48)
- * are windowed the same way with boxes, on the 2xf16 kernels (the fp32 kernels compute whole tiles): 3.5x on a 512x512x256
- * tomogram, bit-identical. */
+ * are windowed the same way with boxes, on the 2xf16 kernels and (round 5) on the fp32 kernels of exact mode / an overflow
+ * re-run: 3.5x on a 512x512x256 tomogram, bit-identical. */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
 /* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
  * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next

@@ -362,6 +362,53 @@ def test_tile_windows_3d_are_bit_identical(gpu_ctx, case):
         assert fl_win < (0.4 if case == 'nf48_96_48' else 0.8) * fl_full
 
 
+@pytest.mark.parametrize('case', ['golden_nf8', 'nf48_ragged', 'nf48_odd_levels', 'nf48_96_48'])
+def test_tile_windows_3d_on_the_fp32_kernels_are_bit_identical(gpu_ctx, case):
+    """round 5: the fp32 kernels of a 3-D program take boxes too (ConvArgs::wz0 / wz1; conv_mfma DIMS = 3, the per-parity fp32
+    launches, the 1-output-channel tiled kernel), so exact mode (tpz_ctx_set_exact) and an overflow re-run of a tiled tomogram
+    compute what the kept voxels depend on instead of every (patch + 2 * padding)^3 tile in full.  Identical bits with the
+    switch off, and the launches do execute less; also a program whose decoder is not an exact 2x upsampling at some level
+    (fused-loader kernels: windowed like any other fp32 launch)."""
+    from topaz_amd.denoise import Denoise3D
+    from topaz_amd.denoising.models import DenoiseNet
+    if case == 'golden_nf8':
+        z = load_golden('denoise3d_unet3d_nf8')
+        d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
+        vol, patch, pad = z['tomo'], 32, 16
+    else:
+        d = Denoise3D(DenoiseNet('unet-3d', oden.synthetic_unet_sd(13, nf=48, base_width=7, top_width=3, dims=3)))
+        if case == 'nf48_ragged':
+            vol, patch, pad = (np.random.RandomState(31).randn(50, 77, 90) * 2 + 1).astype(np.float32), 32, 16
+        elif case == 'nf48_odd_levels':
+            vol, patch, pad = (np.random.RandomState(33).randn(45, 50, 85) * 2 + 1).astype(np.float32), 40, 20
+        else:
+            vol, patch, pad = np.random.RandomState(32).randn(100, 200, 120).astype(np.float32), 96, 48
+    dm = d.model.device_model
+    t = torch.from_numpy(vol).cuda()
+    split = dm.denoise_3d(t, patch, pad).cpu().numpy()           # the default path, for reference
+    try:
+        gpu_ctx.set_exact(True)
+        gpu_ctx.set_roi(False)
+        gpu_ctx.prof_enable(1); gpu_ctx.prof_reset()
+        full = dm.denoise_3d(t, patch, pad).cpu().numpy()
+        fl_full = gpu_ctx.prof_get(0)[2] + gpu_ctx.prof_get(1)[2]
+        gpu_ctx.set_roi(True)
+        gpu_ctx.prof_reset()
+        win = dm.denoise_3d(t, patch, pad).cpu().numpy()
+        fl_win = gpu_ctx.prof_get(0)[2] + gpu_ctx.prof_get(1)[2]
+    finally:
+        gpu_ctx.set_roi(True)
+        gpu_ctx.set_exact(False)
+        gpu_ctx.prof_enable(False)
+    assert np.isfinite(full).all()
+    assert np.array_equal(full, win)
+    assert _err(win, split) <= ATOL
+    if case == 'golden_nf8':
+        assert _err(win, load_golden('denoise3d_unet3d_nf8')['p32_16']) <= ATOL
+    print(f'{case} (fp32 kernels): {fl_full / 1e12:.2f} TFLOP in full, {fl_win / 1e12:.2f} with windows')
+    assert fl_win < (0.4 if case == 'nf48_96_48' else 0.85) * fl_full
+
+
 def test_batched_tiles_with_mixed_source_chunks(gpu_ctx, monkeypatch):
     """A two-source plane-stacked launch whose chunks mix both tensors (conv_split MODE 3: widths of a user-trained 3-D U-Net
     whose first source does not fill whole chunks; forced here by TPZ_NO_SRCMAJOR, read when the model is loaded) has no

@@ -69,6 +69,9 @@ struct ConvArgs {
     // at (wy0, wx0).  Whole tensor: 0, 0, Hout, Wout (conv_window_default; wy1 == 0 means "not set").  wx0 % 4 == 0 keeps the
     // 16-byte granules of the x4 loader aligned.
     int wy0, wx0, wy1, wx1;
+    // ... and, 3-D, the planes [wz0, wz1) of the launch lattice (a tile of a tiled tomogram keeps its centre in z as well);
+    // wz1 == 0: not set (launch_mfma / launch_conv_direct default it to [0, Dout))
+    int wz0, wz1;
     int xcd_swizzle;          // 1: remap workgroup ids so that each XCD owns a contiguous run of tiles
     int stagger_first;        // workgroups with a linear id below this belong to the first generation
     int stagger_sleeps;       // s_sleep(127) repeats for the odd wave slot of the first generation (0 = off)
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int ty = byz % a.tiles_y;
     const int tz = byz / a.tiles_y;
     const int y0 = a.wy0 + (ty / D) * (C::TH * D) + (ty % D);
-    const int z0 = (C::DIMS == 3) ? (tz / D) * (C::TD * D) + (tz % D) : 0;
+    const int z0 = (C::DIMS == 3) ? a.wz0 + (tz / D) * (C::TD * D) + (tz % D) : 0;
     const int x0 = a.wx0 + bx * C::TW;
     // The LDS tile starts PADA = roundup4(pad) pixels left of x0, so every 4-float LDS granule maps to a
     // 16-byte aligned global run when the row pitch is a multiple of 4 floats; B reads shift by PADA - pad.
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             const int ti_z = trow / C::TH, ti_y = trow % C::TH;
             const int oy = y0 + ti_y * D, oz = (C::DIMS == 3) ? z0 + ti_z * D : 0;
             const int ox = x0 + (n % NFC) * 16 + l15;
-            if ((oy < a.wy1) && (ox < a.wx1) && (oz < a.Dout)) {
+            if ((oy < a.wy1) && (ox < a.wx1) && (oz < a.wz1)) {
                 // position in the full output tensor (identity unless this is a phase launch)
                 const int fz = oz * a.os + a.ooz, fy = oy * a.os + a.ooy, fx = ox * a.os + a.oox;
                 const size_t pix_res = (size_t)(C::DIMS == 3 ? fz + a.res_crop : 0) * plane_res +
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             float h = hsum[n];
             h += __shfl_xor(h, 16, 64);
             h += __shfl_xor(h, 32, 64);
-            if (l4 == 0 && oy < a.wy1 && ox < a.wx1 && oz < a.Dout) {
+            if (l4 == 0 && oy < a.wy1 && ox < a.wx1 && oz < a.wz1) {
                 h += a.head_b;
                 if (a.norm_out) h = h * out_scale + out_shift;
                 a.head_out[(size_t)(oz * a.os + a.ooz) * plane_o + (size_t)(oy * a.os + a.ooy) * a.Wfull + (ox * a.os + a.oox)] = h;

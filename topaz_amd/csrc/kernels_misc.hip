@@ -19,8 +19,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs a, cons
                                                           int KZ, int dil) {
     const int ox = a.wx0 + blockIdx.x * 64 + (threadIdx.x & 63);       // (launch window: ConvArgs::wy0 .. wx1)
     const int oy = a.wy0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int oz = blockIdx.z % a.Dout;
-    const int co = blockIdx.z / a.Dout;
+    const int nz = a.wz1 - a.wz0;                                      // (planes of the launch window)
+    const int oz = a.wz0 + (int)(blockIdx.z % nz);
+    const int co = blockIdx.z / nz;
     if (ox >= a.wx1 || oy >= a.wy1) return;
     float out_scale = 1.f, out_shift = 0.f;
     if (a.nrm && a.norm_out) { out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
     __shared__ __attribute__((aligned(16))) float tile[CC * CS];
     const int tid = threadIdx.x;
     const int sx = tid & 15, sy = (tid >> 4) % TH, sz = (tid >> 4) / TH;
-    const int x0 = a.wx0 + blockIdx.x * TW, y0 = a.wy0 + blockIdx.y * TH, z0 = blockIdx.z * TD;
+    const int x0 = a.wx0 + blockIdx.x * TW, y0 = a.wy0 + blockIdx.y * TH, z0 = a.wz0 + blockIdx.z * TD;
     float out_scale = 1.f, out_shift = 0.f;
     if (a.nrm && a.norm_out) { out_scale = a.nrm[2]; out_shift = a.nrm[3]; }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
         }
     }
     const int oy = y0 + sy, oz = z0 + sz;
-    if (oy < a.wy1 && oz < a.Dout) {
+    if (oy < a.wy1 && oz < a.wz1) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int ox = x0 + sx * 4 + p;
@@ -123,19 +124,20 @@ __global__ __launch_bounds__(256) void conv_cout1_tiled_kernel(const ConvArgs a,
 hipError_t launch_conv_direct(const ConvArgs& a_in, const float* d_w, int K, int KZ, int dil, hipStream_t s) {
     ConvArgs a = a_in;
     if (a.wy1 <= 0) { a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout; }      // no window: the whole tensor
-    const int wh = a.wy1 - a.wy0, ww = a.wx1 - a.wx0;
+    if (a.wz1 <= 0 || a.Dout <= 1) { a.wz0 = 0; a.wz1 = a.Dout > 1 ? a.Dout : 1; }
+    const int wh = a.wy1 - a.wy0, ww = a.wx1 - a.wx0, wd = a.wz1 - a.wz0;
     if (KZ == 1 && dil == 1 && a.Cout == 1 && (K == 3 || K == 5)) {
         dim3 grid((ww + 63) / 64, (wh + 15) / 16, 1);
         if (K == 3) hipLaunchKernelGGL((conv_cout1_tiled_kernel<3, 2>), grid, dim3(256), 0, s, a, d_w);
         else hipLaunchKernelGGL((conv_cout1_tiled_kernel<5, 2>), grid, dim3(256), 0, s, a, d_w);
         return hipGetLastError();
     }
-    if (KZ == 3 && K == 3 && dil == 1 && a.Cout == 1 && (a.Dout + 3) / 4 <= 65535) {
-        dim3 grid((ww + 63) / 64, (wh + 3) / 4, (a.Dout + 3) / 4);
+    if (KZ == 3 && K == 3 && dil == 1 && a.Cout == 1 && (wd + 3) / 4 <= 65535) {
+        dim3 grid((ww + 63) / 64, (wh + 3) / 4, (wd + 3) / 4);
         hipLaunchKernelGGL((conv_cout1_tiled_kernel<3, 3>), grid, dim3(256), 0, s, a, d_w);
         return hipGetLastError();
     }
-    dim3 grid((ww + 63) / 64, (wh + 3) / 4, a.Dout * a.Cout);
+    dim3 grid((ww + 63) / 64, (wh + 3) / 4, wd * a.Cout);
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, a, d_w, K, KZ, dil);
     return hipGetLastError();
 }

@@ -1281,9 +1281,11 @@ static int launch_mfma(tpz_ctx* ctx, const ConvKernelInfo& ki, ConvArgs& a, int 
     a.xcd_swizzle = 1;
     if (a.wy1 <= 0) { a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout; }      // no window: the whole lattice
     else flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
+    if (a.wz1 <= 0 || ki.dims != 3) { a.wz0 = 0; a.wz1 = std::max(a.Dout, 1); }  // no z window (every 2-D launch): the whole depth
+    else flops *= (double)(a.wz1 - a.wz0) / a.Dout;
     a.tiles_x = (a.wx1 - a.wx0 + ki.TW - 1) / ki.TW;
     a.tiles_y = (a.wy1 - a.wy0 + ki.TH * ki.D - 1) / (ki.TH * ki.D) * ki.D;
-    a.tiles_z = ki.dims == 3 ? (a.Dout + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
+    a.tiles_z = ki.dims == 3 ? (a.wz1 - a.wz0 + ki.TD * ki.D - 1) / (ki.TD * ki.D) * ki.D : 1;
     a.stagger_first = a.stagger_sleeps = 0;
     // phase stagger of the two workgroups per CU (conv_mfma.h); only worth it for many generations
     if ((long long)a.tiles_x * a.tiles_y >= 4096) {
@@ -1312,6 +1314,10 @@ static void set_window(ConvArgs& a, const Rect& need, int scale = 1) {
     a.wy1 = std::min(a.Hout, (need.y1 + scale - 1) / scale);
     a.wx1 = std::min(a.Wout, (need.x1 + scale - 1) / scale);
     a.wy1 = std::max(a.wy1, a.wy0 + 1); a.wx1 = std::max(a.wx1, a.wx0 + 1);
+    if (a.Dout > 1) {          // 3-D: the planes of the box
+        a.wz0 = std::min(a.Dout - 1, need.z0 / scale);
+        a.wz1 = std::max(a.wz0 + 1, std::min(a.Dout, (need.z1 + scale - 1) / scale));
+    }
 }
 
 // conv(cat(upsample2x(s1), s2)) by output parity (prepare_phases): 2^dims plain launches over s1 that write the
@@ -1339,8 +1345,8 @@ static int run_conv_phases(tpz_ctx* ctx, const LayerRT& rt, const ConvArgs& base
         a.os = 2; a.oox = px; a.ooy = py; a.ooz = pz;
         a.n_chunks = ph.n_chunks_low;
         a.cog_inner = 1;
-        a.wy0 = a.wx0 = a.wy1 = a.wx1 = 0;
-        if (L.dims == 2) set_window(a, dst.need, 2);
+        a.wy0 = a.wx0 = a.wy1 = a.wx1 = a.wz0 = a.wz1 = 0;
+        set_window(a, dst.need, 2);
         const double fl = 2.0 * L.cout * ph.c1 * std::pow((double)ph.k1, L.dims) * (double)s1.D * s1.H * s1.W;
         if (launch_mfma(ctx, *ph.ki_low, a, ph.n_cog_low, fl)) return 1;
     }
@@ -1895,7 +1901,7 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
     a.slope = L.slope;
     if (L.head) { a.head_out = dst.p; a.out = nullptr; }
     else a.out = dst.p;
-    if (L.dims == 2) set_window(a, dst.need);          // patched denoise: only what the kept centre depends on (need_regions)
+    set_window(a, dst.need);          // patched / tiled denoise: only what the kept centre depends on (need_regions)
     const double flops = 2.0 * L.cout * L.cin * std::pow((double)L.k, L.dims) * (double)dst.D * dst.H * dst.W;
     if (rt.ki) {
         const ConvKernelInfo& ki = split_out ? *rt.ki_stem_split : *rt.ki;    // same tile and weight packing
@@ -1914,7 +1920,8 @@ static int run_conv(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const Slot*
         const ConvArgs ac = a;
         const float* wp_ = rt.d_wpk;
         const int k = L.k, kz = L.dims == 3 ? L.k : 1, dil = L.dil;
-        hipError_t e = enqueue(ctx, 1, a.wy1 > 0 ? flops * (a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout) : flops, nullptr,
+        hipError_t e = enqueue(ctx, 1, a.wy1 > 0 ? flops * (a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout) *
+                                                       (a.wz1 > 0 ? (double)(a.wz1 - a.wz0) / a.Dout : 1.0) : flops, nullptr,
                                0.0, [=](hipStream_t st) { return launch_conv_direct(ac, wp_, k, kz, dil, st); });
         HIPCHK(ctx, e);
     }
@@ -1957,7 +1964,8 @@ static std::vector<Rect> need_regions(const tpz_model* m, int D0, int H0, int W0
     };
     if (!keep.on || !m->ctx->roi_enabled || nl == 0) return need;
     const int dims = D0 > 1 ? 3 : 2;
-    if (dims == 3 && !split) return bail(1);
+    // (round 5: the fp32 kernels of a 3-D program take boxes as well -- ConvArgs::wz0 / wz1 -- so exact mode and an overflow
+    // re-run of a tiled tomogram no longer compute every tile in full)
     // shapes of all slots
     std::vector<int> Ds(m->n_slots, 1), Hs(m->n_slots, 0), Ws(m->n_slots, 0);
     Ds[0] = D0; Hs[0] = H0; Ws[0] = W0;
