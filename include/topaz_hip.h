@@ -258,6 +258,11 @@ long long tpz_prof_launches(tpz_ctx* ctx);
  * are windowed the same way with boxes, on the 2xf16 kernels and (round 5) on the fp32 kernels of exact mode / an overflow
  * re-run: 3.5x on a 512x512x256 tomogram, bit-identical. */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
+/* The 3x3 32 -> 32 layers of the 32-unit detectors (resnet8_u32 / resnet16_u32: topaz/model/features/resnet.py:108-204 filled)
+ * run on a persistent kernel that keeps the layer's packed weights in the LDS (csrc/conv_rw.h); on = 0 (TPZ_NO_RW=1 at load
+ * time) sends them to the general 2xf16 tile again.  Same tensors either side; results agree to rounding (another summation
+ * order), each within 1e-4 of the reference. */
+int tpz_ctx_set_rw(tpz_ctx* ctx, int on);
 /* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
  * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next
  * tile under the last chunk of the current one.  mode 0: never (TPZ_NO_PERSIST=1), 1: large launches outside the patch lanes

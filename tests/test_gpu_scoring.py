@@ -406,3 +406,40 @@ def test_large_frame_is_scored_in_tiles(gpu_ctx):
         a, b = (R if y0 > 0 else 0), (R if x0 > 0 else 0)
         c, d = (ref.shape[0] - R if y1 < H else ref.shape[0]), (ref.shape[1] - R if x1 < W else ref.shape[1])
         assert np.abs(y[y0 + a:y0 + c, x0 + b:x0 + d] - ref[a:c, b:d]).max() <= 1e-4
+
+
+@pytest.mark.parametrize('name', ['resnet8_u32', 'resnet16_u32', 'resnet8_bn_u32'])
+def test_weights_resident_kernel_for_the_32_unit_detectors(gpu_ctx, name):
+    """The 3x3 32 -> 32 ResidA layers (resnet.py:108-204 filled: dilation 1 / 2 / 4, plain / residual / residual + eval-BN; nine
+    of resnet16_u32's 17 layers) run on a persistent kernel that keeps the layer's weights in the LDS (csrc/conv_rw.h: no
+    per-step DMA, plan or barrier) instead of the general 2xf16 tile.  Image sizes that do not divide the 8 x 32 tile, the
+    CLI's raw-count case through range scaling, the fp32 oracle to 1e-4 both ways, the two kernels against each other to
+    rounding (another summation order), and the launches really are the new kernel's."""
+    from topaz_amd.model.classifier import LinearClassifier
+    from topaz_amd.model.factory import load_model
+    if name.endswith('_bn_u32'):
+        sd = oscoring.synthetic_resnet_sd('resnet8', 32, 5, bn=True)
+        m, arch = LinearClassifier('resnet8', sd), 'resnet8'
+    else:
+        m, arch = load_model(name), name.split('_')[0]
+        sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    rs = np.random.RandomState(64)
+    for shape, gain, offset in (((333, 401), 1.0, 0.0), ((512, 640), 400.0, 3000.0)):
+        x = (rs.randn(*shape) * gain + offset).astype(np.float32)
+        ref = oscoring.score(arch, sd, x)
+        tol = max(ATOL, 3e-6 * float(np.abs(ref).max()))
+        gpu_ctx.prof_enable(1); gpu_ctx.prof_reset()
+        try:
+            y = _score(m, x)
+            names_on = [k[0] for k in gpu_ctx.prof_kernels()]
+            gpu_ctx.set_rw(False)
+            gpu_ctx.prof_reset()
+            y_gen = _score(m, x)
+            names_off = [k[0] for k in gpu_ctx.prof_kernels()]
+        finally:
+            gpu_ctx.set_rw(True)
+            gpu_ctx.prof_enable(False)
+        assert any('conv_split_rw_kernel' in n for n in names_on) and not any('conv_split_rw_kernel' in n for n in names_off)
+        e_rw, e_gen, e_ab = np.abs(y - ref).max(), np.abs(y_gen - ref).max(), np.abs(y - y_gen).max()
+        print(f'{name} {shape} x*{gain}+{offset}: |rw - oracle| {e_rw:.2e}  |general - oracle| {e_gen:.2e}  |rw - general| {e_ab:.2e}')
+        assert e_rw <= tol and e_gen <= tol and e_ab <= tol

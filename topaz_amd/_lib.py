@@ -85,6 +85,7 @@ _SIGNATURES = {
     'tpz_ctx_set_tiling': (C.c_int, [_P, C.c_longlong, C.c_int]),
     'tpz_prof_launches': (C.c_longlong, [_P]),
     'tpz_ctx_set_roi': (C.c_int, [_P, C.c_int]),
+    'tpz_ctx_set_rw': (C.c_int, [_P, C.c_int]),
     'tpz_ctx_set_persist': (C.c_int, [_P, C.c_int, C.c_int]),
     'tpz_model_split_stats': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     'tpz_model_split_layers': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),

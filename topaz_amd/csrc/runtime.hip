@@ -14,6 +14,7 @@
 #include "../../include/topaz_hip.h"
 #include "conv_registry.h"
 #include "conv_split_registry.h"
+#include "conv_rw.h"
 #include "kernels_misc.h"
 
 using namespace tpz;
@@ -166,6 +167,7 @@ struct tpz_ctx {
     unsigned* d_absmax = nullptr; // exponent histogram of launch_range_fit (256 words, kept zeroed)
     bool range_scaling = getenv("TPZ_NO_RANGE") == nullptr;       // tpz_ctx_set_range
     bool raster = getenv("TPZ_NO_RASTER") == nullptr;             // tpz_ctx_set_raster: patch raster of the 8-wave tiles' grids
+    bool rw_enabled = true;                   // tpz_ctx_set_rw: the weights-resident kernel for 3x3 32 -> 32 layers (conv_rw.h)
     // internal tiling of tpz_model_forward (run_image): 2-D images above tile_limit_px pixels are scored in tile_size^2 tiles
     long long tile_limit_px = 40LL << 20;
     int tile_size = 4096;
@@ -499,6 +501,10 @@ struct LayerRT {
     const SplitKernelInfo* ks_last = nullptr;
     float* d_wlast = nullptr;                  // ... or (k = 3 / 5, few input channels) the vector-ALU stencil conv_cout1_split_kernel:
                                                // its weights [kz][cell][kx][ky][8] fp32
+    // 3x3 32 -> 32 layers (dilation 1 / 2 / 4) of the 32-unit detectors: the weights-resident persistent kernel (conv_rw.h),
+    // its weights packed with all 4 cells of a tap per step
+    void* d_w_rw = nullptr;
+    float* d_ws_rw = nullptr;
     const SplitKernelInfo* ks_pool = nullptr;  // twin of ks / ks_stem with the following 2x2 max-pool fused (EPI_POOL)
     // ResidA blocks that change width, y = [bn1](conv1(t) + proj(h)) (resnet.py:185-202): on the 2xf16 path the 1x1 projection is
     // FOLDED into conv1's K loop (SplitArgs::fold_cells) -- the projection layer is then skipped (folded_into = index of conv1)
@@ -1188,6 +1194,18 @@ static int prepare_split(tpz_ctx* ctx, tpz_model* m, const float* blob) {
             if (upload_split_weights(ctx, m, *rt.ks, blob + L.w_off, L.cout, L.cin, &rt.s_n_cog, &rt.s_n_chunks,
                                      &rt.d_wsplit, &rt.d_wscale, L.dims == 3 ? L.k : 1)) return 1;
             any_split = true;
+            // the weights-resident kernel for the 3x3 32 -> 32 layers (conv_rw.h): same tensors either side, its own weight order
+            static const bool no_rw = getenv("TPZ_NO_RW") != nullptr;                      // A/B switch
+            if (!no_rw && L.dims == 2 && L.k == 3 && L.cin == 32 && L.cout == 32 && L.src2 < 0 && !L.head &&
+                (L.dil == 1 || L.dil == 2 || L.dil == 4) && rt.ks->epi <= EPI_RES_POST) {
+                SplitKernelInfo rw;
+                memset(&rw, 0, sizeof rw);
+                rw.K = rw.KX = 3; rw.D = L.dil; rw.MT = 32; rw.CC = 4; rw.cont = 1; rw.Q = 36; rw.SPS = 1;
+                rw.W_STEP_BYTES = 2 * (32 / 16) * 1024;
+                rw.cont_slot = [](int q) { return SplitSlot{(q / 4) / 3, (q / 4) % 3, q % 4}; };
+                int n_cog = 0, n_chunks = 0;
+                if (upload_split_weights(ctx, m, rw, blob + L.w_off, L.cout, L.cin, &n_cog, &n_chunks, &rt.d_w_rw, &rt.d_ws_rw)) return 1;
+            }
         }
         if (rt.sphase.valid) any_split = true;
     }
@@ -1385,6 +1403,36 @@ static void set_window(SplitArgs& a, const Rect& need, int scale = 1, int grow_x
 }
 
 
+// the weights-resident kernel (conv_rw.h) for a 3x3 32 -> 32 layer: window and tile grid as launch_split, one persistent
+// workgroup per CU
+static int launch_rw(tpz_ctx* ctx, SplitArgs& a, int dil, int epi, double flops) {
+    static char names[3][3][96];
+    const int di = dil == 1 ? 0 : dil == 2 ? 1 : 2;
+    if (!names[di][epi][0])
+        snprintf(names[di][epi], sizeof names[di][epi], "conv_split_rw_kernel<K=3x3,D=%d,MT=32,TH=8,TW=32,W=4,EPI=%d> (weights resident)", dil, epi);
+    if (a.wy1 < 0) {
+        a.wy1 = -a.wy1;
+        flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
+    } else {
+        a.wy0 = a.wx0 = 0; a.wy1 = a.Hout; a.wx1 = a.Wout;
+    }
+    a.tiles_x = (a.wx1 - a.wx0 + 31) / 32;
+    a.tiles_y = (a.wy1 - a.wy0 + 8 * dil - 1) / (8 * dil) * dil;
+    const long long nt = (long long)a.tiles_x * a.tiles_y;
+    if (nt >= (1LL << 30)) return fail(ctx, "conv grid too large");
+    a.n_tiles = (int)nt;
+    if ((size_t)a.cells_in * a.Hin * a.Win * 16 >= ((size_t)1 << 32) - 16)
+        return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
+    const int wgs = std::max(8, ctx->n_cus / 8 * 8);
+    const double wy = a.wy1 - a.wy0, wx = a.wx1 - a.wx0, span = 2.0 * dil;
+    double bytes = (double)a.cells_in * 32.0 * std::min((double)a.Hin, wy + span) * std::min((double)a.Win, wx + span) +
+                   32.0 * a.cells_out * wy * wx * (a.res ? 2.0 : 1.0) + 36864.0;
+    const SplitArgs ac = a;
+    hipError_t e = enqueue(ctx, 0, flops, names[di][epi], bytes, [=](hipStream_t st) { return launch_conv_rw(ac, dil, epi, wgs, st); });
+    if (e != hipSuccess) return fail(ctx, "conv_rw launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 // one conv layer on the 2xf16 path: split source (and residual), split output or fused fp32 head
 // (fold: the input of a folded 1x1 projection, split cells -- the layer then runs ks_fold with the projection's channels
 // appended to its K loop, no residual, eval-BN already inside weights and bias)
@@ -1451,6 +1499,11 @@ static int run_conv_split(tpz_ctx* ctx, const LayerRT& rt, const Slot& s1, const
         return launch_split(ctx, ks, a, rt.f_n_cog, flops);
     }
     set_window(a, dst.need);           // (a pooled dst keeps its need in the coordinates of the un-pooled conv output)
+    if (rt.d_w_rw && !pooled && !s2 && !ctx->rec_on && ks.epi <= EPI_RES_POST && L.dims == 2 && ctx->rw_enabled) {
+        a.wpk = reinterpret_cast<const uint4*>(rt.d_w_rw);
+        a.wscale = rt.d_ws_rw;
+        return launch_rw(ctx, a, L.dil, ks.epi, flops);
+    }
     return launch_split(ctx, ks, a, rt.s_n_cog, flops);
 }
 
@@ -2700,6 +2753,11 @@ int tpz_ctx_set_raster(tpz_ctx* ctx, int on) {
     return 0;
 }
 
+int tpz_ctx_set_rw(tpz_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, "ctx is NULL");
+    ctx->rw_enabled = on != 0;
+    return 0;
+}
 int tpz_ctx_set_range(tpz_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, "ctx is NULL");
     ctx->range_scaling = on != 0;

@@ -87,6 +87,10 @@ class Context:
         """patch windows of tpz_denoise_2d: each layer of a patch computes only what the kept centre depends on (default on)"""
         check(self.lib.tpz_ctx_set_roi(self.handle, 1 if on else 0), self.handle)
 
+    def set_rw(self, on: bool = True) -> None:
+        """the weights-resident kernel for the 3x3 32 -> 32 layers of the 32-unit detectors (csrc/conv_rw.h; default on)"""
+        check(self.lib.tpz_ctx_set_rw(self.handle, 1 if on else 0), self.handle)
+
     def set_persist(self, mode: int = 1, workgroups: int = 0) -> None:
         """persistent workgroups of the 2xf16 convolutions: 0 never, 1 large launches (default), 2 every eligible launch with
         `workgroups` workgroups (0: one per grid slot)"""
