@@ -19,6 +19,12 @@
 // formats either side: the layers before and after do not know.  A pixel's sum runs over (tap, cell) in a fixed order whatever
 // tile it falls into (internal tiling, windows: bit-identical); it is another order than conv_split's (chunk-major), so the two
 // kernels agree to rounding, not to the bit.
+// Measured (profiles/r05_rw_ab.txt, 4096^2): plain 1.02 - 1.16 ms per layer (276 - 316 TFLOP/s; conv_split: 1.44 - 1.71), with
+// the residual 1.36 - 1.45 ms (226 - 236; 1.75 - 1.97).  That is 3.8 - 4.7 TB/s of algorithmic bytes (32 channels in, 32 out,
+// 32 of residual at 4 B each against 18.4 kFLOP per pixel: 72 / 48 flop per byte) -- the layers are now HBM-bound, which is why
+// a second form with TWO phase-shifted 4-wave groups per workgroup (one group's MFMAs under the other's epilogue and DMA issue;
+// 8 x 16 tiles, four input buffers) measured 5 - 15 % SLOWER: more halo bytes per pixel for matrix-pipe time that was not the
+// limit.  It is not kept.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,6 +32,15 @@
 #include "conv_split.h"
 
 namespace tpz {
+
+// workgroup barrier that does NOT drain this wave's vector-memory operations: `__syncthreads()` is a fence + barrier, and the fence
+// waits vmcnt(0) whenever an LDS-DMA (a pending LDS write on the VM counter) or a store is outstanding -- which here is always
+// (the next tile's input, the previous tile's stores): every barrier then exposed a full memory latency.  What the barriers of
+// these kernels order is LDS traffic only: each wave has waited for its OWN DMA pieces (vmcnt) before it arrives, and its LDS
+// reads are complete (lgkmcnt) -- cdna_hip_programming.md, "Pipelining across barriers".
+__device__ __forceinline__ void rw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int D_>
 struct RwCfg {
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
         const int cy0 = y0, cx0 = x0;
         // every wave's pieces of the current tile are in the LDS (each waited for its own behind its previous K loop) and every
         // wave is done reading the other buffer
-        __syncthreads();
+        rw_barrier();
         // per pixel fragment: output / residual offsets of this lane (window test folded into the offset)
         unsigned ovo[NW], rvo[NW];
 #pragma unroll
@@ -182,27 +197,45 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
 #pragma unroll
             for (int n = 0; n < NW; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned char* bl = lds + b_lane + buf * C::IN_BUF;
-#pragma unroll
-        for (int s = 0; s < C::NSTEP; ++s) {
+        f16x8 bh[2][NW], bo[2][NW], ah[2][MW], ao[2][MW];
+        auto load_step = [&](int s, int slot) {
             const int ky = s / C::K, kx = s - ky * C::K;
             const int tap = (ky * C::ITW + kx * D) * 16;
-            f16x8 bh[NW], bo[NW];
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
-                bh[n] = *reinterpret_cast<const f16x8*>(bl + tap + b_off(n));
-                bo[n] = *reinterpret_cast<const f16x8*>(bl + tap + b_off(n) + C::PLANE_BYTES);
+                bh[slot][n] = *reinterpret_cast<const f16x8*>(bl + tap + b_off(n));
+                bo[slot][n] = *reinterpret_cast<const f16x8*>(bl + tap + b_off(n) + C::PLANE_BYTES);
             }
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(lds + a_lane + s * C::W_STEP_BYTES + m * 1024);
-                const f16x8 ao = *reinterpret_cast<const f16x8*>(lds + a_lane + s * C::W_STEP_BYTES + (MW + m) * 1024);
-#pragma unroll
-                for (int n = 0; n < NW; ++n) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bo[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao, bh[n], acc[m][n], 0, 0, 0);
-                }
+                ah[slot][m] = *reinterpret_cast<const f16x8*>(lds + a_lane + s * C::W_STEP_BYTES + m * 1024);
+                ao[slot][m] = *reinterpret_cast<const f16x8*>(lds + a_lane + s * C::W_STEP_BYTES + (MW + m) * 1024);
             }
+        };
+        load_step(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NW + 2 * MW, 0);
+#pragma unroll
+        for (int s = 0; s < C::NSTEP; ++s) {
+            const int cur = s & 1;
+            // issue order pinned: the fragment reads of step s + 1, then the MFMAs of step s (one wave per SIMD: nothing else
+            // hides an LDS round trip)
+            if (s + 1 < C::NSTEP) {
+                load_step(s + 1, cur ^ 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NW + 2 * MW, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NW, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bo[cur][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ao[cur][m], bh[cur][n], acc[m][n], 0, 0, 0);
         }
         // the next tile's pieces (issued a K loop ago), the residual cells: landed.  The stores below are NOT waited for here --
         // they drain under the next tile's K loop

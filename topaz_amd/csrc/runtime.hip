@@ -1409,7 +1409,7 @@ static int launch_rw(tpz_ctx* ctx, SplitArgs& a, int dil, int epi, double flops)
     static char names[3][3][96];
     const int di = dil == 1 ? 0 : dil == 2 ? 1 : 2;
     if (!names[di][epi][0])
-        snprintf(names[di][epi], sizeof names[di][epi], "conv_split_rw_kernel<K=3x3,D=%d,MT=32,TH=8,TW=32,W=4,EPI=%d> (weights resident)", dil, epi);
+        snprintf(names[di][epi], sizeof names[di][epi], "conv_split_rw_kernel<K=3x3,D=%d,MT=32,EPI=%d> (weights resident)", dil, epi);
     if (a.wy1 < 0) {
         a.wy1 = -a.wy1;
         flops *= (double)(a.wy1 - a.wy0) * (a.wx1 - a.wx0) / ((double)a.Hout * a.Wout);
