@@ -514,3 +514,40 @@ def test_fcnn_runs_wholly_on_the_2xf16_path(gpu_ctx):
     finally:
         gpu_ctx.set_exact(False)
     assert _err(a, b) <= ATOL and before[2] == 0
+
+
+def test_unet_nf32_weights_resident_layers_with_windows_and_lanes(gpu_ctx):
+    """A user-trained U-Net of 32 filters: its encoder convs (3x3, 32 -> 32) are the shape the weights-resident kernel takes
+    (csrc/conv_rw.h) -- here inside a PATCHED denoise, i.e. with launch windows (each patch computes what its kept centre depends
+    on) and, unbatched, on the two patch lanes.  A batched pass keeps those layers on the general 2xf16 tile (its launches are
+    merged across patches).  Unbatched with windows == unbatched without (bit-identical); unbatched vs batched to rounding
+    (another summation order in those layers); both within 1e-4 of the oracle."""
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(17, nf=32, base_width=11, top_width=5)
+    d = Denoise(DenoiseNet('unet', sd))
+    x = (np.random.RandomState(5).randn(700, 820) * 1.5 + 0.3).astype(np.float32)
+    ref = oden.denoise('unet', sd, x, 256, 96)
+    try:
+        gpu_ctx.set_batch(0)
+        gpu_ctx.prof_enable(1); gpu_ctx.prof_reset()
+        a = d.denoise(x, 256, 96)
+        names = [k[0] for k in gpu_ctx.prof_kernels()]
+        gpu_ctx.prof_enable(False)
+        gpu_ctx.set_roi(False)
+        a_full = d.denoise(x, 256, 96)
+        gpu_ctx.set_roi(True)
+        gpu_ctx.set_rw(False)
+        a_gen = d.denoise(x, 256, 96)
+        gpu_ctx.set_rw(True)
+        gpu_ctx.set_batch(8)
+        b = d.denoise(x, 256, 96)
+    finally:
+        gpu_ctx.set_batch(8)
+        gpu_ctx.set_roi(True)
+        gpu_ctx.set_rw(True)
+        gpu_ctx.prof_enable(False)
+    assert any('conv_split_rw_kernel' in n for n in names), names
+    assert np.array_equal(a, a_full)
+    assert _err(a, ref) <= ATOL and _err(b, ref) <= ATOL and _err(a_gen, ref) <= ATOL
+    assert _err(a, b) <= 2e-5 and np.array_equal(a_gen, b)
