@@ -658,13 +658,18 @@ def main():
         args.steps = len(parallel.shard_indices(args.images, rank, world))       # this rank's share of the fixed job
     if args.dry_run:
         return dry_run(args, rank, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # the rank's GPU (its local rank; TOPAZ_AMD_SHARE_GPU=1 + TOPAZ_AMD_DIST_BACKEND=gloo: a rehearsal of the multi-rank bench on a
+    # box with fewer GPUs than ranks -- several ranks on one device, the exchange steps over gloo on host tensors) and where the
+    # tensors of the collectives live (the GPU under RCCL)
+    gpu = parallel.rank_device(local_rank)
+    torch.cuda.set_device(gpu)
+    dev = torch.device('cuda', gpu)
+    cdev = parallel.collective_device(local_rank)
     from topaz_amd import runtime as rt
-    ctx = rt.get_context(local_rank)
+    ctx = rt.get_context(gpu)
 
     # the collective really spans the job's ranks: an all_reduce of ones over RCCL (1 without a process group)
-    rccl_world = int(parallel.sum_over_ranks(1.0, dev))
+    rccl_world = int(parallel.sum_over_ranks(1.0, cdev))
     # this rank's micrographs, resident in HBM before the timed region (global index = rank + i*world); a long strong-scaling
     # share cycles through a bounded set of resident micrographs
     n_res = min(args.steps, 8) if args.scaling == 'strong' else args.steps
@@ -685,9 +690,9 @@ def main():
 
     # ---- the timed region: barrier + synchronize on both sides, exactly K steps, then the one exchange step
     torch.cuda.synchronize(dev)
-    parallel.barrier(dev)
+    parallel.barrier(cdev)
     launches0 = ctx.launches()
-    sampler = GpuSampler(local_rank)
+    sampler = GpuSampler(gpu)
     sampler.__enter__()                                  # (joined after the timed region: its 25 ms sleep is not part of the job)
     t0 = time.perf_counter()
     step_t, mem_used = [], {}
@@ -716,18 +721,18 @@ def main():
     scs, cds = [p[0] for p in picks], [p[1] for p in picks]
     have_picks = cds[0] is not None
     if have_picks and world > 1:
-        parallel.gather_pick_tables(ids, scs, cds, dev)       # RCCL: all_gather of counts + two gathers to rank 0
+        parallel.gather_pick_tables(ids, scs, cds, cdev)       # RCCL: all_gather of counts + two gathers to rank 0
     torch.cuda.synchronize(dev)
     t_gather = time.perf_counter() - t0 - t_compute
-    parallel.barrier(dev)
+    parallel.barrier(cdev)
     dt = time.perf_counter() - t0
     # every rank's own compute time per micrograph: stragglers (host contention between the ranks' launch threads, a slow
     # device) show as a spread between min and max
     sampler.__exit__()
-    rank_ms = parallel.gather_scalars(1e3 * t_compute / max(1, args.steps), dev)
-    total_steps = int(parallel.sum_over_ranks(float(args.steps), dev))
-    dt = parallel.max_over_ranks(dt, dev)
-    t_gather = parallel.max_over_ranks(t_gather, dev)
+    rank_ms = parallel.gather_scalars(1e3 * t_compute / max(1, args.steps), cdev)
+    total_steps = int(parallel.sum_over_ranks(float(args.steps), cdev))
+    dt = parallel.max_over_ranks(dt, cdev)
+    t_gather = parallel.max_over_ranks(t_gather, cdev)
     n_picks = int(sum(int(s.numel()) for s in scs)) if have_picks else 0
 
     # ---- roofline: per-kernel HIP-event times of the launches of the timed steps, per step

@@ -127,3 +127,23 @@ def test_two_ranks_share_the_gpu_denoise_and_denoise3d_exit_status(gpu_ctx, tmp_
     r = _topaz(a3 + ['--gpus', '2', '-o', t2, tp], env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(os.path.join(t1, 'tomo.mrc'), 'rb').read() == open(os.path.join(t2, 'tomo.mrc'), 'rb').read()
+
+
+def test_bench_two_ranks_share_the_gpu(gpu_ctx):
+    """`python bench.py --gpus 2` as the driver's scaling run would execute it -- self-launched ranks, barrier + max-over-ranks
+    timing, the gather of REAL pick tables, one JSON line from rank 0 -- rehearsed on one GPU: both ranks drive GPU 0
+    (TOPAZ_AMD_SHARE_GPU=1), the collectives run over gloo on host tensors.  Not a measurement (two ranks share one device);
+    what is checked is the multi-rank code path of the bench itself."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOPAZ_AMD_SHARE_GPU='1', TOPAZ_AMD_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '1024',
+           '--patch-size', '512', '--patch-padding', '128', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['config']['images_total'] == 4 and d['value'] > 0
+    assert len(d['rank_ms_per_step']['all']) == 2 and d['config']['picks_per_image'] > 10
+    assert d['roofline']['achieved'] > 0 and 'configs' not in d and 'cpu_baseline' not in d
