@@ -551,3 +551,33 @@ def test_unet_nf32_weights_resident_layers_with_windows_and_lanes(gpu_ctx):
     assert np.array_equal(a, a_full)
     assert _err(a, ref) <= ATOL and _err(b, ref) <= ATOL and _err(a_gen, ref) <= ATOL
     assert _err(a, b) <= 2e-5 and np.array_equal(a_gen, b)
+
+
+@pytest.mark.parametrize('nf', [20, 12, 40])
+def test_unet_of_any_width_runs_wholly_on_the_2xf16_path(gpu_ctx, nf):
+    """UDenoiseNet (skip connections at every level: decoder sources of 2 nf + nf channels) with widths that are not multiples
+    of 16: loaded zero-padded (runtime.hip widen_program) -- every layer on the f16 matrix cores, whole image and patched,
+    within 1e-4 of the oracle, and equal to the exact-fp32 kernels within the same bound."""
+    import warnings
+    from topaz_amd.denoise import Denoise
+    from topaz_amd.denoising.models import DenoiseNet
+    sd = oden.synthetic_unet_sd(40 + nf, nf=nf, base_width=11, top_width=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        d = Denoise(DenoiseNet('unet', sd))
+    n_conv, n_split, off = d.model.device_model.split_layers()
+    assert n_split == n_conv, off
+    x = (np.random.RandomState(nf).randn(300, 420) * 1.2 - 0.4).astype(np.float32)
+    ref_whole, ref_p = oden.denoise('unet', sd, x, -1), oden.denoise('unet', sd, x, 128, 64)
+    a, b = d.denoise(x, -1), d.denoise(x, 128, 64)
+    assert _err(a, ref_whole) <= ATOL and _err(b, ref_p) <= ATOL
+    gpu_ctx.set_exact(True)
+    try:
+        a32 = d.denoise(x, -1)
+    finally:
+        gpu_ctx.set_exact(False)
+    assert _err(a, a32) <= ATOL and dm_reruns(d) == 0
+
+
+def dm_reruns(d):
+    return d.model.device_model.split_stats()[2]
