@@ -922,8 +922,7 @@ def main():
                                'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS'))},
             'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': [round(v, 3) for v in rank_ms]},
             'vs_baseline': None,
-            'dtype': 'f32 (fp32 MFMA kernels only: TPZ_EXACT_FP32 is set)' if os.environ.get('TPZ_EXACT_FP32') else
-                     'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
+            'dtype': 'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
                      'multiply-add accumulated in f32 -- fp32-level error, fp32-MFMA re-run on f16-range overflow; '
                      'NMS in fp32; the exact-fp32-multiply rate is reported as exact_fp32)',
             'data': 'synthetic (N(0,1) micrographs seed 1000+i; seeded random weights of the named architectures)',

@@ -215,12 +215,18 @@ int tpz_transpose_2d(tpz_ctx* ctx, const float* d_in, int rows, int cols, float*
  * (topaz_amd/csrc/conv_split.h): fp32-level accuracy at several times the fp32-MFMA rate.  The rule per layer: it takes the 2xf16
  * path when a conv_split kernel exists for its shape (2-D and plane-stacked 3-D alike: the 3-D scoring networks run there too),
  * otherwise it stays on its fp32-MFMA kernel; layers with a PReLU slope > 1 always do.  An activation beyond the f16 range is detected on the device and that
- * image is re-run on the fp32 kernels, so results never depend on the range.  tpz_ctx_set_exact(ctx, 1) (or TPZ_EXACT_FP32=1
- * in the environment) pins the fp32 kernels.
+ * image is re-run on the fp32 kernels, so results never depend on the range.  tpz_ctx_set_exact(ctx, 1) pins the
+ * fp32 kernels.
  * tpz_model_split_stats: whether the model is eligible, images finished on the 2xf16 path, images re-run in fp32. */
 int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
+/* Debug switches.  The library's A/B switches (TPZ_NO_ROI, TPZ_EXACT_FP32, TPZ_NO_LANES, ... -- the list is the DebugEnv struct of
+ * topaz_amd/csrc/rt_internal.h) exist for tools/ and tests/; a variable left in a user's environment must not change how a job
+ * computes, so the library reads them in ONE function and only when TPZ_DEBUG=1 is set as well.  tpz_debug_switches writes the
+ * space-separated names of the switches that are in effect right now into buf ("" when none: always so without TPZ_DEBUG=1)
+ * and returns their number.  Needs no device. */
+int tpz_debug_switches(char* buf, int buf_len);
 /* Range scaling of the scoring pass (tpz_model_forward of a program that ends in the linear head), on by default
- * (TPZ_NO_RANGE=1 / on = 0: off).  `topaz extract` scores micrographs as they come (topaz/extract.py:234-249 does not normalise), and
+ * (on = 0: off).  `topaz extract` scores micrographs as they come (topaz/extract.py:234-249 does not normalise), and
  * a raw-count image (mean 10^3 .. 10^4) would leave the f16 range in the very first layer and send the whole image to the fp32
  * kernels.  A scoring network is positively homogeneous in (input, biases) jointly -- convolutions, PReLU / ReLU, max-pools,
  * residual adds, eval-BN affines, the linear head --, so it is run on x * 2^-s with every bias-like vector scaled by 2^-s and its
@@ -231,15 +237,15 @@ int tpz_ctx_set_exact(tpz_ctx* ctx, int on);
 int tpz_ctx_set_range(tpz_ctx* ctx, int on);
 /* Patch lanes: tpz_denoise_2d / _3d enqueue the independent patches / tiles of an image alternately on two auxiliary
  * streams (own workspace each), so that one patch's small, latency-bound launches run under its neighbour's large ones.
- * On by default (TPZ_NO_LANES=1 in the environment or on = 0 here: everything on the ctx stream, e.g. to time kernels in
- * isolation).  on = 2 .. 4 (or TPZ_LANES=n): that many lanes; more than two measured no gain on the 4096^2 pipeline
+ * On by default (on = 0 here: everything on the ctx stream, e.g. to time kernels in
+ * isolation).  on = 2 .. 4: that many lanes; more than two measured no gain on the 4096^2 pipeline
  * (profiles/r03_lanes.txt).  Results are bit-identical either way. */
 int tpz_ctx_set_lanes(tpz_ctx* ctx, int on);
 /* Batched patches (2xf16 path): tpz_denoise_2d / _3d record the launches of up to n (<= 8) independent patches / tiles and issue
  * them layer by layer, the same layer of all n as ONE grid (conv_split_multi_kernel): the deep levels of a U-Net are 16-tile
  * launches on a 256-CU chip, ~400 of them per micrograph (denoise.py:299-323 runs the patches one after another).  Consecutive
  * batches alternate on the patch lanes above (a batch's elementwise launches and small grids run under the other batch's large
- * ones: profiles/r04_batch_lanes_ab.txt).  Default n = 8 (TPZ_BATCH=n, TPZ_NO_BATCH=1 in the environment); n = 0: off -- single
+ * ones: profiles/r04_batch_lanes_ab.txt).  Default n = 8; n = 0: off -- single
  * patches then alternate on the lanes, as do the fp32 kernels (exact mode, overflow re-run) always.  Results are bit-identical
  * either way.
  * Every image of a batch has a workspace of its own and two batches are in flight: the batch is cut to what fits 90 % of the
@@ -253,25 +259,25 @@ long long tpz_prof_launches(tpz_ctx* ctx);
  * patch_size + 2*padding tile), so each layer computes only the rectangle of its tensor that those pixels depend on (the
  * U-Net's receptive field is ~230 pixels, the CLI's default padding 500).  The statistics of the normalisation are still the
  * whole padded patch's; every kept pixel is computed exactly as before -- the output is bit-identical with the switch off
- * (TPZ_NO_ROI=1 in the environment or on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones.
+ * (on = 0 here).  Both paths: the 2xf16 kernels and, under tpz_ctx_set_exact, the fp32 ones.
  * The tiles of tpz_denoise_3d (denoise.py:340-377: patch^3 voxels kept of a (patch + 2*padding)^3 tile, 1/8 at the CLI's 96 / 48)
  * are windowed the same way with boxes, on the 2xf16 kernels and (round 5) on the fp32 kernels of exact mode / an overflow
  * re-run: 3.5x on a 512x512x256 tomogram, bit-identical. */
 int tpz_ctx_set_roi(tpz_ctx* ctx, int on);
 /* The 3x3 32 -> 32 layers of the 32-unit detectors (resnet8_u32 / resnet16_u32: topaz/model/features/resnet.py:108-204 filled)
- * run on a persistent kernel that keeps the layer's packed weights in the LDS (csrc/conv_rw.h); on = 0 (TPZ_NO_RW=1 at load
+ * run on a persistent kernel that keeps the layer's packed weights in the LDS (csrc/conv_rw.h); on = 0 (with TPZ_DEBUG=1: TPZ_NO_RW=1 at load
  * time) sends them to the general 2xf16 tile again.  Same tensors either side; results agree to rounding (another summation
  * order), each within 1e-4 of the reference. */
 int tpz_ctx_set_rw(tpz_ctx* ctx, int on);
 /* Persistent workgroups of the 2xf16 convolutions (conv_split.h, MODE 4): a plain single-source layer with several tiles per
  * workgroup slot is launched as CUs x workgroups-per-CU workgroups that walk the tiles and fetch the first chunk of their next
- * tile under the last chunk of the current one.  mode 0: never (TPZ_NO_PERSIST=1), 1: large launches outside the patch lanes
+ * tile under the last chunk of the current one.  mode 0: never, 1: large launches outside the patch lanes
  * (default), 2: every eligible launch, with `workgroups` of them (0: one grid slot each) -- the form the tests use to run
  * small images through many tiles per workgroup.  Results are bit-identical in every mode. */
 int tpz_ctx_set_persist(tpz_ctx* ctx, int mode, int workgroups);
 /* Patch raster of the large 8-wave launches (conv_split.h, xcd_swizzle 2): the 32 tiles an XCD's CUs hold at a time form an
  * 8 x 4 block of neighbouring tiles (rows taken phase-major for dilated layers), so that their halos overlap in that XCD's L2,
- * instead of a row-major run that shares columns only.  On by default (TPZ_NO_RASTER=1 / on = 0: row-major runs).  Same
+ * instead of a row-major run that shares columns only.  On by default (on = 0: row-major runs).  Same
  * arithmetic per tile: results are bit-identical. */
 int tpz_ctx_set_raster(tpz_ctx* ctx, int on);
 /* Internal tiling of tpz_model_forward: a 2-D image of more than limit_px pixels (default 40 Mi: beyond a 6400^2 frame) through a

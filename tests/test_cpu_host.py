@@ -22,6 +22,39 @@ def test_library_exports_every_declared_symbol():
     _lib.load_library()                               # prototypes attach without error
 
 
+def test_stray_debug_variables_change_nothing_without_TPZ_DEBUG(monkeypatch):
+    """The library's A/B switches (TPZ_EXACT_FP32, TPZ_NO_ROI, ...) are read by ONE function and only under TPZ_DEBUG=1
+    (VERDICT r05 item 7): a variable left in a user's environment must not change the arithmetic or the schedule of a job."""
+    import ctypes as C
+    from topaz_amd import _lib
+    lib = _lib.load_library()
+    buf = C.create_string_buffer(512)
+    for k in ('TPZ_DEBUG', 'TPZ_EXACT_FP32', 'TPZ_NO_ROI', 'TPZ_NO_RANGE', 'TPZ_NO_WIDEN', 'TPZ_BATCH', 'TPZ_LANES'):
+        monkeypatch.delenv(k, raising=False)
+    assert lib.tpz_debug_switches(buf, 512) == 0 and buf.value == b''
+    for k, v in (('TPZ_EXACT_FP32', '1'), ('TPZ_NO_ROI', '1'), ('TPZ_NO_RANGE', '1'), ('TPZ_NO_WIDEN', '1'), ('TPZ_BATCH', '2'),
+                 ('TPZ_LANES', '3')):
+        monkeypatch.setenv(k, v)
+    assert lib.tpz_debug_switches(buf, 512) == 0 and buf.value == b'', buf.value      # stray variables: nothing in effect
+    monkeypatch.setenv('TPZ_DEBUG', '0')
+    assert lib.tpz_debug_switches(buf, 512) == 0
+    monkeypatch.setenv('TPZ_DEBUG', '1')
+    assert lib.tpz_debug_switches(buf, 512) == 6
+    assert buf.value.split() == [b'exact_fp32', b'no_roi', b'no_range', b'no_widen', b'batch', b'lanes']
+    # and no other getenv in the device library's sources
+    import glob, os, re
+    root = os.path.dirname(os.path.abspath(_lib.__file__))
+    uses = []
+    for f in glob.glob(os.path.join(root, 'csrc', '*.h*')):
+        src = open(f).read()
+        if not f.endswith('rt_core.hip'):
+            assert 'getenv' not in src, f
+        else:
+            body = src[src.index('DebugEnv debug_env() {'):]
+            body = body[:body.index('\n}\n') + 3]
+            assert src.count('getenv') == body.count('getenv'), 'getenv outside debug_env()'
+
+
 def test_layer_struct_matches_header():
     from topaz_amd._lib import TpzLayer
     header = open(os.path.join(ROOT, 'include', 'topaz_hip.h')).read()

@@ -411,7 +411,7 @@ def test_tile_windows_3d_on_the_fp32_kernels_are_bit_identical(gpu_ctx, case):
 
 def test_batched_tiles_with_mixed_source_chunks(gpu_ctx, monkeypatch):
     """A two-source plane-stacked launch whose chunks mix both tensors (conv_split MODE 3: widths of a user-trained 3-D U-Net
-    whose first source does not fill whole chunks; forced here by TPZ_NO_SRCMAJOR, read when the model is loaded) has no
+    whose first source does not fill whole chunks; forced here by the debug switch TPZ_NO_SRCMAJOR -- honoured under TPZ_DEBUG=1 only, read when the model is loaded) has no
     batched instantiation: rec_flush must issue those launches one by one instead of failing the whole batched pass with
     'conv_split launch failed: invalid value' (round-4 advisor finding).  Same bits as the unbatched lanes path and as the
     source-major model."""
@@ -420,9 +420,11 @@ def test_batched_tiles_with_mixed_source_chunks(gpu_ctx, monkeypatch):
     z = load_golden('denoise3d_unet3d_nf8')
     tomo = torch.from_numpy(z['tomo']).cuda()
     ref = Denoise3D(DenoiseNet('unet-3d', golden_sd(z))).model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()
+    monkeypatch.setenv('TPZ_DEBUG', '1')
     monkeypatch.setenv('TPZ_NO_SRCMAJOR', '1')
     d = Denoise3D(DenoiseNet('unet-3d', golden_sd(z)))
     monkeypatch.delenv('TPZ_NO_SRCMAJOR')
+    monkeypatch.delenv('TPZ_DEBUG')
     try:
         gpu_ctx.set_batch(8)
         batched = d.model.device_model.denoise_3d(tomo, 32, 16).cpu().numpy()

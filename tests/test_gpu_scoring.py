@@ -443,3 +443,26 @@ def test_weights_resident_kernel_for_the_32_unit_detectors(gpu_ctx, name):
         e_rw, e_gen, e_ab = np.abs(y - ref).max(), np.abs(y_gen - ref).max(), np.abs(y - y_gen).max()
         print(f'{name} {shape} x*{gain}+{offset}: |rw - oracle| {e_rw:.2e}  |general - oracle| {e_gen:.2e}  |rw - general| {e_ab:.2e}')
         assert e_rw <= tol and e_gen <= tol and e_ab <= tol
+
+
+def test_partial_program_of_odd_width_ending_in_a_pool_keeps_its_channels(gpu_ctx):
+    """A program whose widths have no 2xf16 kernel is loaded zero-padded to multiples of 16 channels (widen_program); the
+    tensor the program RETURNS keeps its width also when the program ends in a pool behind the padded conv (round-5 advisor
+    finding: the caller got 16 channels, four of them zero, and the shape depended on which kernels exist)."""
+    import torch.nn.functional as F
+    from topaz_amd.runtime import DeviceModel, LayerProgram
+    rs = np.random.RandomState(5)
+    w0 = (rs.randn(12, 1, 3, 3) * 0.3).astype(np.float32)
+    w1 = (rs.randn(12, 12, 3, 3) * 0.15).astype(np.float32)
+    b0, b1 = (rs.randn(12) * 0.1).astype(np.float32), (rs.randn(12) * 0.1).astype(np.float32)
+    x = rs.randn(1, 1, 70, 90).astype(np.float32)
+    t = F.leaky_relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w0), torch.from_numpy(b0), padding=1), 0.1)
+    t = F.leaky_relu(F.conv2d(t, torch.from_numpy(w1), torch.from_numpy(b1), padding=1), 0.1)
+    for tail, ref in (('maxpool2', F.max_pool2d(t, 2)), ('maxpool', F.max_pool2d(t, 3, stride=1))):
+        p = LayerProgram(2)
+        s = p.conv(0, w0, b0, pad=1, slope=0.1)
+        s = p.conv(s, w1, b1, pad=1, slope=0.1)
+        s = p.maxpool2(s) if tail == 'maxpool2' else p.maxpool(s, 3, 1)
+        y = DeviceModel(p, gpu_ctx).forward(torch.from_numpy(x).cuda()).cpu()
+        assert tuple(y.shape) == tuple(ref.shape), (tail, y.shape, ref.shape)
+        assert (y - ref).abs().max().item() <= ATOL

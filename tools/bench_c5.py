@@ -1,5 +1,5 @@
 """C5 alone (BASELINE config 5: unet-3d on a 512x512x256 tomogram, 96/48 tiles), best of three runs -- the row of
-tools/bench_configs.py that the A/B switches TPZ_NO_SRCMAJOR / TPZ_NO_POOL3D / TPZ_LANES are measured on."""
+tools/bench_configs.py that the A/B switches TPZ_NO_SRCMAJOR / TPZ_NO_POOL3D / TPZ_LANES (with TPZ_DEBUG=1) are measured on."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from tools import synth_weights as sw

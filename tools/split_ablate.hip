@@ -6,6 +6,7 @@
 #include <string>
 #include "conv_split.h"
 using namespace tpz;
+#define TPZ_C ,
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -136,7 +137,7 @@ int bench(const char* name, int cin, int cout, int H) {
     return 0;
 }
 
-template <class C, int EPI>
+template <class C, int EPI, int ABLX = 0>
 int quick(const char* name, int cin, int cout, int H) {
     const int span = C::D * (C::K - 1);
     const int Ho = H - span;
@@ -175,7 +176,7 @@ int quick(const char* name, int cin, int cout, int H) {
            n_st * a.cog_inner);
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(flag, 0, 256);
-        float ms = run<C, EPI, 2048>(a, grid, 10);
+        float ms = run<C, EPI, 2048 | ABLX>(a, grid, 10);
         unsigned long long c[6];
         hipMemcpy(c, flag, 48, hipMemcpyDeviceToHost);
         // cycles per workgroup (11 launches accumulated): whole kernel, prologue (tables + first tile + wait), K loop, epilogue
@@ -262,6 +263,19 @@ int main(int argc, char** argv) {
         bench<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w S=2 RES", 64, 64, 2048);
         bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
         bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "epi") {
+        // round 6: paired 16-byte epilogue stores / residual loads (v_permlane16_swap) against the 8-byte ones (ABL 262144)
+#define EPI_AB(CFG, E, label, cin, cout, H) quick<CFG, E, 262144>(label " [8-byte accesses]", cin, cout, H); quick<CFG, E>(label " [16-byte, paired]", cin, cout, H);
+        EPI_AB(SplitCfg<3 TPZ_C 8 TPZ_C 128 TPZ_C 16 TPZ_C 32 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 1>, EPI_RES, "K3 D8 MT128 8w RES", 128, 128, 2048)
+        EPI_AB(SplitCfg<3 TPZ_C 4 TPZ_C 128 TPZ_C 16 TPZ_C 32 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 2>, EPI_PLAIN, "K3 D4 MT128 8w S=2", 128, 128, 2048)
+        EPI_AB(SplitCfg<3 TPZ_C 2 TPZ_C 64 TPZ_C 16 TPZ_C 48 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 1>, EPI_PLAIN, "K3 D2 MT64 8w 16x48", 64, 64, 2052)
+        EPI_AB(SplitCfg<3 TPZ_C 4 TPZ_C 64 TPZ_C 16 TPZ_C 48 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 1>, EPI_RES, "K3 D4 MT64 8w 16x48 RES", 64, 64, 2056)
+        EPI_AB(SplitCfg<3 TPZ_C 1 TPZ_C 96 TPZ_C 8 TPZ_C 32 TPZ_C 2 TPZ_C 4 TPZ_C 3 TPZ_C 1>, EPI_PLAIN, "K3 D1 MT96 4w (U-Net 96->96 at 1012^2)", 96, 96, 1014)
+        EPI_AB(SplitCfg<3 TPZ_C 1 TPZ_C 128 TPZ_C 8 TPZ_C 32 TPZ_C 2 TPZ_C 4 TPZ_C 3 TPZ_C 1>, EPI_PLAIN, "K3 D1 MT128 4w (sub-pixel dec1.0)", 104, 256, 1014)
+        EPI_AB(SplitCfg<5 TPZ_C 1 TPZ_C 32 TPZ_C 8 TPZ_C 32 TPZ_C 2 TPZ_C 4 TPZ_C 5 TPZ_C 2>, EPI_PLAIN, "K5 D1 MT32 4w S=2 (dec1.2 64->32)", 64, 32, 2028)
+        EPI_AB(SplitCfg<3 TPZ_C 1 TPZ_C 48 TPZ_C 8 TPZ_C 32 TPZ_C 2 TPZ_C 4 TPZ_C 3 TPZ_C 1>, EPI_PLAIN, "K3 D1 MT48 4w", 48, 48, 1024)
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "ab") {

@@ -98,6 +98,7 @@ _SIGNATURES = {
     'tpz_prof_get': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     'tpz_prof_get_kernel_bytes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     'tpz_prof_mfma_sustained': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'tpz_debug_switches': (C.c_int, [C.c_char_p, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

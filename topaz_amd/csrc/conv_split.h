@@ -377,6 +377,7 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 //   128 no per-step weight DMA   256 no per-step input DMA
 //   4096 input DMA without the offset table (contiguous dummy source)   8192 input DMA from a 2 MB window (always L2 hits)
 //   16384 DMA issued but never waited for inside the K loop (what the latency of a stage's own prefetch costs)
+//   262144 the round-5 epilogue accesses: 8-byte stores / residual loads per lane instead of the paired 16-byte ones
 //   2048 clock probe: every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
 //        to the two 64-bit counters behind a.flag -> effective clock of the variant (DVFS: the chip runs at its power limit)
 // MODE: what the instantiation can do besides a plain single-source 2-D conv -- bit 0: a second source (`in2`: fused upsample +
@@ -961,6 +962,35 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
             }
         }
         const unsigned cp16_o = (unsigned)(cplane_out * 16), cp16_r = (unsigned)(cplane_res * 16);       // bytes of one cell plane
+        // WIDE accesses (round 6): an MFMA accumulator fragment leaves a lane with HALF a cell (4 of its 8 channels) of one
+        // pixel, so the stores above are 8 bytes per lane and a wave's epilogue is 2 * MW * NW store instructions (and as many
+        // residual loads) -- the epilogue is bound by their issue, not by bytes (cdna_hip_programming.md T21).  Pixel fragments
+        // are therefore handled in PAIRS (n0, n1): one v_permlane16_swap per dword exchanges the odd 16-lane rows of n0's
+        // register with the even rows of n1's, after which the lanes of an even row (l4 = 0, 2) hold BOTH halves of their cell of
+        // pixel n0 and the lanes of an odd row both halves of the same cell of pixel n1: one 16-byte store per lane and plane,
+        // half the instructions, every byte where it went before.  The residual cells come in the same way (16-byte loads,
+        // un-swapped by the same instruction: the swap is an involution).
+        constexpr bool WIDE = (NW % 2 == 0) && EPI != EPI_HEAD && EPI != EPI_PLAIN_F32 && EPI != EPI_POOL && (ABL & 262144) == 0;
+        constexpr int NP = WIDE ? NW / 2 : 1;
+        unsigned ovw[NP], rvw[NP];
+        if constexpr (WIDE) {
+            // (computed from the fragment's coordinates, not selected from opix[] / rpix[]: a lane-dependent choice between two
+            // array elements is compiled into an indexed scratch access)
+            const int odd = l4 & 1;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int fr = odd ? (2 * q + 1) / NFC : (2 * q) / NFC, fc = odd ? (2 * q + 1) % NFC : (2 * q) % NFC;
+                const int oy = y0 + (wave * C::RPW + fr) * D;
+                const int ox = x0 + fc * 16 + l15;
+                bool ok = oy < a.wy1 && ox < a.wx1;
+                if constexpr ((ABL & 1) != 0 || (ABL & 64) != 0) ok = ok && (a.slope == 12345.f);
+                const int cy = oy < a.Hout ? oy : a.Hout - 1, cx = ox < a.Wout ? ox : a.Wout - 1;
+                const int fy = cy * a.os + ooy, fx = cx * a.os + oox;
+                const unsigned po = (unsigned)(fy * a.Wfull + fx), pr = (unsigned)((fy + a.res_crop) * a.Wres + fx + a.res_crop);
+                ovw[q] = ok ? po * 16u + (unsigned)(l4 >> 1) * (unsigned)(cplane_out * 16) : OOB;
+                rvw[q] = pr * 16u + (unsigned)(l4 >> 1) * (unsigned)(cplane_res * 16);
+            }
+        }
         const unsigned zo16 = (unsigned)(zoff_out * 16), zr16 = (unsigned)(zoff_res * 16);                // ... to this tile's plane
         const size_t pl16_o = plane_out * 16, pl16_r = plane_res * 16;                                    // hi -> lo
         const unsigned char* const out8 = reinterpret_cast<const unsigned char*>(a.out);
@@ -995,6 +1025,7 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
         // itself: res and out may be the same tensor -- the in-place skip launch of a per-parity layer -- where every lane
         // reads exactly the cells it writes later, so running ahead of the stores of OTHER fragments is safe.)
         constexpr bool RESID = (EPI == EPI_RES || EPI == EPI_RES_POST) && !(ABL & 1) && !(ABL & 32);
+        // (WIDE: entries 2q / 2q + 1 of rh hold dwords 0-1 / 2-3 of pair q's 16-byte cell until use_res un-swaps them in place)
         u32x2 rhb[2][NW], rlb[2][NW];
         auto load_res = [&](int m, u32x2 (&rh)[NW], u32x2 (&rl)[NW]) {
             const Frag f = frag_of(m);
@@ -1003,11 +1034,28 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
             const unsigned char* rb8 = res8 + ((size_t)((unsigned)f.cell0 * (unsigned long long)cp16_r) + ex16);
             const __amdgpu_buffer_rsrc_t srd_rh = make_srd(rb8, nrec);
             const __amdgpu_buffer_rsrc_t srd_rl = make_srd(rb8 + pl16_r, nrec);
+            if constexpr (WIDE) {
 #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                rh[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rh, (int)rvo[n], 0, 0);
-                rl[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rl, (int)rvo[n], 0, 0);
+                for (int q = 0; q < NP; ++q) {
+                    const u32x4 ch = __builtin_amdgcn_raw_buffer_load_b128(srd_rh, (int)rvw[q], 0, 0);
+                    const u32x4 cl = __builtin_amdgcn_raw_buffer_load_b128(srd_rl, (int)rvw[q], 0, 0);
+                    rh[2 * q] = (u32x2){ch[0], ch[1]}; rh[2 * q + 1] = (u32x2){ch[2], ch[3]};
+                    rl[2 * q] = (u32x2){cl[0], cl[1]}; rl[2 * q + 1] = (u32x2){cl[2], cl[3]};
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    rh[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rh, (int)rvo[n], 0, 0);
+                    rl[n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rl, (int)rvo[n], 0, 0);
+                }
             }
+        };
+        // the loaded cells of pair q -> the half cells of fragments 2q and 2q + 1 in accumulator layout
+        auto unswap_res = [&](u32x2 (&r)[NW], int q) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(r[2 * q].x, r[2 * q + 1].x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(r[2 * q].y, r[2 * q + 1].y, false, false);
+            r[2 * q] = (u32x2){s0[0], s1[0]};
+            r[2 * q + 1] = (u32x2){s0[1], s1[1]};
         };
         if constexpr (RESID) load_res(0, rhb[0], rlb[0]);
 #pragma unroll
@@ -1077,8 +1125,12 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
                 }
                 continue;
             }
+            unsigned keep_h[2] = {0u, 0u}, keep_l[2] = {0u, 0u};     // WIDE: the split halves of the pair's first fragment
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
+                if constexpr (WIDE && RESID) {
+                    if ((n & 1) == 0) { unswap_res(rh, n >> 1); unswap_res(rl, n >> 1); }
+                }
                 f32x2 v[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1109,8 +1161,22 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h0 & okmask[n]));
                     bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h1 & okmask[n]));
-                    __builtin_amdgcn_raw_buffer_store_b64(hi, srd_oh, (int)ovo[n], 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(lo, srd_ol, (int)ovo[n], 0, 0);
+                    if constexpr (WIDE) {
+                        if ((n & 1) == 0) {
+                            keep_h[0] = h0; keep_h[1] = h1; keep_l[0] = l0; keep_l[1] = l1;
+                        } else {
+                            const auto sh0 = __builtin_amdgcn_permlane16_swap(keep_h[0], h0, false, false);
+                            const auto sh1 = __builtin_amdgcn_permlane16_swap(keep_h[1], h1, false, false);
+                            const auto sl0 = __builtin_amdgcn_permlane16_swap(keep_l[0], l0, false, false);
+                            const auto sl1 = __builtin_amdgcn_permlane16_swap(keep_l[1], l1, false, false);
+                            const u32x4 chi = {sh0[0], sh1[0], sh0[1], sh1[1]}, clo = {sl0[0], sl1[0], sl0[1], sl1[1]};
+                            __builtin_amdgcn_raw_buffer_store_b128(chi, srd_oh, (int)ovw[n >> 1], 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(clo, srd_ol, (int)ovw[n >> 1], 0, 0);
+                        }
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(hi, srd_oh, (int)ovo[n], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lo, srd_ol, (int)ovo[n], 0, 0);
+                    }
                 }
             }
         }

@@ -932,9 +932,7 @@ hipError_t launch_conv_cout1_split(const void* in, const float* wt, float* out, 
     if (K == 5 && KZ == 1) return launch_cout1_cfg<5, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
     if (K == 3 && KZ == 1) return launch_cout1_cfg<3, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
     if (K == 3) {
-        static const int zp = getenv("TPZ_COUT1_ZP") ? atoi(getenv("TPZ_COUT1_ZP")) : 2;          // A/B switch
-        if (zp == 1) return launch_cout1_cfg<3, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
-        if (zp == 4) return launch_cout1_cfg<3, 32, 4>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
+        // (ZP = 1 / 4 were measured in round 5, profiles/r05_last_conv_ab.txt: 2 it is)
         return launch_cout1_cfg<3, 32, 2>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);
     }
     if (K == 5) return launch_cout1_cfg<5, 32, 1>(in, wt, out, res, nrm, norm_out, bias, cells, KZ, D, H, W, z0, z1, y0, y1, x0, x1, s);

@@ -55,6 +55,7 @@ __device__ __forceinline__ f32x2 join2(unsigned hi, unsigned lo) {
 // arithmetic.  Bit-identical to split2 (v - (float)hi is exact in fp32, so there is one rounding, to f16, either way); checked
 // against the conversions on the MI355X by tools/mix_probe.hip.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split2m(f32x2 v, unsigned& hi, unsigned& lo) {
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
     unsigned l;
