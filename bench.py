@@ -86,12 +86,17 @@ def _cpu_model() -> str:
     return 'unknown'
 
 
+# CPUs this process was allowed before the rank pinned itself next to its GPU (main): the CPU-baseline legs use one whole
+# socket of THOSE, not the GPU's NUMA node
+_ORIG_AFFINITY = None
+
+
 def one_socket_cores():
     """(physical cores of ONE socket, CPU ids of their first hardware threads) from /proc/cpuinfo, restricted to the CPUs this
     process may run on -- BASELINE.md 3 / SURVEY 8(d) time the CPU path on the physical cores of one socket.  (None, None) where
     the topology cannot be read."""
     try:
-        allowed = set(os.sched_getaffinity(0))
+        allowed = set(_ORIG_AFFINITY) if _ORIG_AFFINITY is not None else set(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         allowed = None
     cores, cur = {}, {}
@@ -144,8 +149,10 @@ class OneSocket:
                 pass
 
 
-def cpu_baseline(models, args):
-    """The oracle (torch-CPU convs, C NMS) timed on this host.  Default: a bounded sample of the step's own units of work --
+def cpu_baseline(models, args, keep=None):
+    """The oracle (torch-CPU convs, C NMS) timed on this host.  `keep` (a dict) receives the leg's own inputs and outputs -- the
+    patch it denoised, the crop it scored, the logits, the picks -- for the parity check of the GPU path (parity_vs_oracle).
+    Default: a bounded sample of the step's own units of work --
     the denoiser on ONE full patch of the -s/-p tiling (2024^2 at the defaults; a 4096^2 micrograph is 16 such crops, 3.0x the
     image), the scorer and the suppression on a --cpu-sample crop (2048^2) -- each scaled by the pixels the
     whole micrograph pushes through that stage.  (Round 2 timed everything on a 1024^2 crop: oneDNN runs small images at a
@@ -156,10 +163,10 @@ def cpu_baseline(models, args):
     full = args.cpu_full
     img = np.random.RandomState(1000).randn(args.size, args.size).astype(np.float32)
     with OneSocket() as sock:
-        return _cpu_baseline(models, args, full, img, sock.cores, sock.pinned)
+        return _cpu_baseline(models, args, full, img, sock.cores, sock.pinned, keep)
 
 
-def _cpu_baseline(models, args, full, img, threads, pinned):
+def _cpu_baseline(models, args, full, img, threads, pinned, keep=None):
     from oracle import denoising as oden
     from oracle import nms as onms
     from oracle import scoring as oscoring
@@ -178,6 +185,8 @@ def _cpu_baseline(models, args, full, img, threads, pinned):
         else:
             P = min(args.size, args.patch_size + 2 * args.patch_padding)
             t0 = time.time(); x = oden.denoise('unet', sd, img[:P, :P].copy(), -1); t = time.time() - t0
+            if keep is not None:
+                keep['denoise_in'], keep['denoise_out'] = img[:P, :P].copy(), x.copy()
             S = P                              # the later stages see what they see in the step: a denoised image
             # pixels the full job pushes through the net with -s/-p patching
             n_px = 0
@@ -198,7 +207,9 @@ def _cpu_baseline(models, args, full, img, threads, pinned):
         t0 = time.time(); logit = oscoring.score('resnet8', sd, x); t = time.time() - t0
         parts['score_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
-        t0 = time.time(); onms.nms2d(logit, args.radius, args.threshold); t = time.time() - t0
+        t0 = time.time(); o_sc, o_co = onms.nms2d(logit, args.radius, args.threshold); t = time.time() - t0
+        if keep is not None:
+            keep['score_in'], keep['logit'], keep['picks'] = x.copy(), logit.copy(), (o_sc, o_co)
         parts['nms_s'] = round(t, 3)
         per_image += t if full else t * full_px / (S * S)
     sample = (f'micrograph 0 at {S}x{S} (the whole workload of one step, nothing scaled), times {parts}' if full else
@@ -210,6 +221,39 @@ def _cpu_baseline(models, args, full, img, threads, pinned):
                          'torch intra-op threads (socket topology not readable: unpinned)',
             'cpu': _cpu_model(), 'host_logical_cpus': os.cpu_count(),
             'sample': sample + '; oracle = torch-CPU fp32 convs (oneDNN), C NMS'}
+
+
+def parity_vs_oracle(models, keep, args, dev):
+    """The GPU path on the very arrays the cpu_baseline leg pushed through the oracle: the patch it
+    denoised, the crop it scored (the ORACLE's denoised pixels, so each stage is compared on identical input), its logits
+    through the device NMS.  Bars: 1e-4 absolute on denoised pixels and logits (north_star), identical pick tables."""
+    from topaz_amd import runtime as rt
+    out = {'atol': 1e-4}
+    if 'denoise_in' in keep and 'denoise' in models:
+        y = models['denoise'][0].denoise_device(torch.from_numpy(keep['denoise_in']).to(dev), -1, 0).cpu().numpy()
+        out['denoise_max_abs'] = float(np.abs(y - keep['denoise_out']).max())
+        out['denoise_on'] = 'x'.join(map(str, keep['denoise_in'].shape)) + ' patch of micrograph 0 (one _denoise call)'
+    if 'logit' in keep and 'score' in models:
+        lg = models['score'][0](torch.from_numpy(keep['score_in']).to(dev)[None, None])[0, 0]
+        out['logit_max_abs'] = float(np.abs(lg.cpu().numpy() - keep['logit']).max())
+        out['logit_range'] = [float(keep['logit'].min()), float(keep['logit'].max())]
+        out['logit_on'] = 'x'.join(map(str, keep['score_in'].shape)) + " crop of the oracle's denoised patch"
+        sc, co = rt.nms(torch.from_numpy(keep['logit']).to(dev), args.radius, args.threshold)
+        o_sc, o_co = keep['picks']
+        out['picks'] = int(len(o_sc))
+        out['picks_equal'] = bool(len(o_sc) == sc.numel() and np.array_equal(co.cpu().numpy(), o_co)
+                                  and np.array_equal(sc.cpu().numpy(), o_sc))
+        # and the chain as a user sees it: picks of the GPU's own logits against the oracle's (a pick may differ where two
+        # competing scores lie within 2e-4 of each other)
+        sc2, co2 = rt.nms(lg, args.radius, args.threshold)
+        a = {tuple(c) for c in co2.cpu().numpy().tolist()}
+        b = {tuple(c) for c in np.asarray(o_co).tolist()}
+        out['picks_differing_end_to_end'] = int(len(a ^ b))
+    out['ok'] = bool(out.get('denoise_max_abs', 0.0) <= 1e-4 and out.get('logit_max_abs', 0.0) <= 1e-4 and
+                     out.get('picks_equal', True))
+    out['what'] = ('HIP path vs oracle on the arrays of the cpu_baseline leg: |denoised pixel| and |logit| deltas (bar 1e-4), the '
+                   "device NMS on the oracle's own logit map (bar: identical coordinates and scores)")
+    return out
 
 
 def kernel_source_sha1() -> str:
@@ -268,7 +312,8 @@ def dry_run(args, rank, world):
                           'steps': args.steps, 'warmup': args.warmup, 'images_gathered': len(tables), 'scaling': args.scaling,
                           'rccl_world': rccl_world,
             'host_placement': {'rank0_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
-                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS'))}, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
+                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS')),
+                               'host_cpus_before_pinning': len(_ORIG_AFFINITY) if _ORIG_AFFINITY is not None else None}, 'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms)},
                           'ms_per_step': 1e3 * dt / max(1, args.steps), 'backend': 'gloo'}))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -638,9 +683,12 @@ def main():
     ap.add_argument('--cpu-full', action='store_true', help='cpu_baseline on one whole micrograph instead of a crop (minutes)')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not record HIP events around the launches of the timed steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='skip the exact_fp32 and pcie_inclusive legs')
+    ap.add_argument('--extras', action='store_true',
+                    help='also run the secondary legs: pcie_inclusive, the A/B legs (row_major_raster, patch_lanes_unbatched, '
+                         'full_patch_tensors), cli_inclusive and a CPU baseline per config (minutes)')
+    ap.add_argument('--no-extras', action='store_true', help='also skip exact_fp32 (the only secondary leg of a default run)')
     ap.add_argument('--no-configs', action='store_true', help='skip the per-config legs (BASELINE configs 2, 3, 5 one by one)')
-    ap.add_argument('--exact-steps', type=int, default=3)
+    ap.add_argument('--exact-steps', type=int, default=2)
     ap.add_argument('--dry-run', action='store_true', help='CPU-only plumbing check over gloo (no hot path, not a measurement)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help="weak (default): every rank times --steps micrographs; strong: BASELINE config 4's FIXED job of --images "
@@ -652,7 +700,13 @@ def main():
     if args.gpus > 1 and not parallel.under_launcher():
         # plain `python bench.py --gpus N`: be the launcher -- one rank process per GPU, rank 0 prints the line
         sys.exit(parallel.launch_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    global _ORIG_AFFINITY
+    if hasattr(os, 'sched_getaffinity'):
+        _ORIG_AFFINITY = sorted(os.sched_getaffinity(0))
     rank, local_rank, world = parallel.init_from_env('gloo' if args.dry_run else None)
+    if world == 1 and not args.dry_run:
+        # a single rank places itself next to its GPU exactly as the ranks of a multi-GPU job do (host_placement in the line)
+        parallel.pin_this_rank(local_rank, 1)
     assert world == args.gpus, f'WORLD_SIZE={world} but --gpus {args.gpus}'
     if args.scaling == 'strong':
         args.steps = len(parallel.shard_indices(args.images, rank, world))       # this rank's share of the fixed job
@@ -695,6 +749,7 @@ def main():
     sampler = GpuSampler(gpu)
     sampler.__enter__()                                  # (joined after the timed region: its 25 ms sleep is not part of the job)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                           # host CPU seconds of this rank process (all its threads)
     step_t, mem_used = [], {}
     if args.scaling == 'strong':
         # the fixed job as a SOAK through the real job path: every step's completion time (a step ends with
@@ -715,6 +770,7 @@ def main():
         picks = [run_step(models, imgs[i % n_res], args) for i in range(args.steps)]
     torch.cuda.synchronize(dev)
     t_compute = time.perf_counter() - t0
+    cpu_compute = time.process_time() - cpu0
     sampler._stop = True
     launches_per_step = (ctx.launches() - launches0) / max(1, args.steps)
     ids = [rank + i * world for i in range(args.steps)]
@@ -730,6 +786,7 @@ def main():
     # device) show as a spread between min and max
     sampler.__exit__()
     rank_ms = parallel.gather_scalars(1e3 * t_compute / max(1, args.steps), cdev)
+    rank_cpu_ms = parallel.gather_scalars(1e3 * cpu_compute / max(1, args.steps), cdev)
     total_steps = int(parallel.sum_over_ranks(float(args.steps), cdev))
     dt = parallel.max_over_ranks(dt, cdev)
     t_gather = parallel.max_over_ranks(t_gather, cdev)
@@ -834,8 +891,12 @@ def main():
             ctx.set_lanes(True)
         hbm_rows.sort(key=lambda r: -r['ms'])
 
-    # ---- extra legs (after the timed region, N = 1 only): exact-fp32 kernels; host-resident input (PCIe-inclusive)
+    # ---- extra legs (after the timed region, N = 1 only).  A default run keeps exact_fp32 (the exact-fp32-multiply twin of
+    # `value`); everything else -- host-resident input, the A/B legs, the CLI from files, a CPU baseline per config -- is behind
+    # --extras, so that the driver's run stays well inside a minute
     extras = {}
+    leg_s = {}
+    t_leg = time.perf_counter()
     if world == 1 and not args.no_extras:
         ctx.set_exact(True)
         try:
@@ -850,6 +911,8 @@ def main():
                                         'denoise patch computes the rectangle the kept centre depends on); the max-pools, the 1x1 '
                                         'projections and the last conv run as layers of their own here (not fused / folded)',
                                 'like_for_like_with': 'value'}
+        leg_s['exact_fp32'] = time.perf_counter() - t_leg
+    if world == 1 and args.extras:
         extras['pcie_inclusive'] = pcie_inclusive(models, host_imgs, args, dev)
         if args.workload != 'denoise':
             # A/B of the patch raster of the 8-wave launches (scoring stage): row-major XCD runs instead of 8 x 4 blocks of tiles
@@ -900,11 +963,16 @@ def main():
             fp32_reruns += int(dm.split_stats()[2])
     configs = None
     if rank == 0 and world == 1 and not args.no_configs and args.workload == 'pipeline':
-        configs = baseline_configs(ctx, models, imgs, args, dev, with_cpu=not args.no_cpu_baseline)
-        try:
-            extras['cli_inclusive'] = cli_inclusive(args, dev)
-        except Exception as e:                               # (a leg of its own: never takes the line down)
-            extras['cli_inclusive'] = {'error': f'{type(e).__name__}: {e}'}
+        t_leg = time.perf_counter()
+        configs = baseline_configs(ctx, models, imgs, args, dev, with_cpu=args.extras and not args.no_cpu_baseline)
+        leg_s['configs'] = time.perf_counter() - t_leg
+        if args.extras:
+            t_leg = time.perf_counter()
+            try:
+                extras['cli_inclusive'] = cli_inclusive(args, dev)
+            except Exception as e:                               # (a leg of its own: never takes the line down)
+                extras['cli_inclusive'] = {'error': f'{type(e).__name__}: {e}'}
+            leg_s['cli_inclusive'] = time.perf_counter() - t_leg
 
     if rank == 0:
         out = {
@@ -919,8 +987,11 @@ def main():
             'scaling': args.scaling,
             'rccl_world': rccl_world,
             'host_placement': {'rank0_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
-                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS'))},
+                               'pinned_to_gpu_numa_node': bool(os.environ.get('TOPAZ_AMD_RANK_CPUS')),
+                               'host_cpus_before_pinning': len(_ORIG_AFFINITY) if _ORIG_AFFINITY is not None else None},
             'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'all': [round(v, 3) for v in rank_ms]},
+            # host CPU time each rank process spent per step (launch thread, runtime, Python): what 8 ranks on one host add up to
+            'rank_host_cpu_ms_per_step': {'max': max(rank_cpu_ms), 'all': [round(v, 3) for v in rank_cpu_ms]},
             'vs_baseline': None,
             'dtype': 'f32 (convs: fp32 operands carried as two f16 halves on the f16 MFMA, three exact products per '
                      'multiply-add accumulated in f32 -- fp32-level error, fp32-MFMA re-run on f16-range overflow; '
@@ -986,8 +1057,17 @@ def main():
         if configs is not None:
             out['configs'] = configs
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(models, args)
+            t_leg = time.perf_counter()
+            keep = {}
+            out['cpu_baseline'] = cpu_baseline(models, args, keep)
+            leg_s['cpu_baseline'] = time.perf_counter() - t_leg
+            # the same arrays through the HIP path: parity as part of the line (and of the exit status)
+            out['parity'] = parity_vs_oracle(models, keep, args, dev)
+        out['leg_seconds'] = {k: round(v, 2) for k, v in leg_s.items()}
         print(json.dumps(out))
+        if 'parity' in out and not out['parity']['ok']:
+            sys.stderr.write(f"bench.py: PARITY FAILED against the oracle: {out['parity']}\n")
+            sys.exit(3)
     if world > 1:
         torch.distributed.destroy_process_group()
 
