@@ -851,8 +851,11 @@ def main():
     # timed region (profiles/r04_mfma_sustained.txt: with full-entropy operands the board holds ~1.9 GHz, not the 2.4 GHz of the
     # dense peak; with zero operands the same loop reaches the nominal rate)
     sustained = None
+    probe_power = None
     if rank == 0 and is_split:
-        tf_rand, clk_rand = ctx.mfma_sustained(300, False)
+        with GpuSampler(gpu) as ps:
+            tf_rand, clk_rand = ctx.mfma_sustained(300, False)
+        probe_power = ps.summary().get('power_w_mean')
         tf_zero, clk_zero = ctx.mfma_sustained(300, True)
         sustained = {
             'f16_dense_tflops': tf_rand, 'fp32_equivalent_tflops': tf_rand / 3.0,
@@ -863,6 +866,23 @@ def main():
                     '0.3 s, operands uniform in [-1, 1] (zero_operand: all zero); no memory traffic.  `frac` above stays against '
                     'the nominal peak; this is the ceiling the board power management leaves for that instruction',
         }
+    # ---- the ENERGY view of the same roofline.  The board runs this step at its power cap from the first launch to the last
+    # (gpu_clock_power.power_w_mean), so a step's time is its energy / the cap: what the matrix pipes alone need for the step's
+    # executed f16 MFMA FLOP (at the pJ / FLOP of the register-resident probe, which runs at the same cap) is the floor
+    energy = None
+    gp = sampler.summary()
+    if sustained and probe_power and gp.get('power_w_mean') and tf_rand > 0:
+        j_step = gp['power_w_mean'] * dt / max(1, args.steps)
+        pj_per_flop = probe_power / (tf_rand * 1e12) * 1e12
+        split_flops = sum(k[3] for k in kernels if k[0].startswith('conv_split'))       # fp32-equivalent, per step, executed
+        j_floor = 3.0 * split_flops * pj_per_flop * 1e-12
+        energy = {'joules_per_micrograph': j_step, 'mfma_floor_joules': j_floor, 'frac': j_floor / j_step if j_step > 0 else None,
+                  'probe_pj_per_f16_flop': pj_per_flop, 'probe_power_w': probe_power,
+                  'f16_mfma_tflop_per_step': 3.0 * split_flops / 1e12,
+                  'what': 'joules = mean board power of the timed region x time per step; floor = the step\'s executed f16 MFMA FLOP '
+                          '(3 per fp32-equivalent FLOP of the conv_split launches timed in the step) x the energy per FLOP of '
+                          'tpz_prof_mfma_sustained (MFMAs from registers, random operands, same power cap).  On a power-capped '
+                          'board frac is the fraction of the step\'s energy -- hence of its time -- that the arithmetic itself needs'}
     cls_f32, cls_split = klass('conv_mfma'), klass('conv_split')
     cls_f32['frac'] = cls_f32['achieved'] / FP32_MFMA_PEAK_TFLOPS
     cls_split['frac'] = cls_split['achieved'] / SPLIT_PEAK_TFLOPS
@@ -1011,6 +1031,7 @@ def main():
             'launches_per_step': launches_per_step,
             'fp32_reruns': fp32_reruns,
             'gpu_clock_power': sampler.summary(),
+            'energy': energy,
             # the dominant kernel = the conv instantiation with the most time in a step (live HIP-event timing of the
             # timed steps' own launches); `achieved` is algorithmic (fp32-equivalent) FLOP/s
             'roofline': {
