@@ -339,6 +339,28 @@ def scoring3d_basic():
             torch.save(m, os.path.join(OUT, 'user_model_conv31_3d_bn_u8.sav'))
 
 
+def scoring3d_conv127():
+    """The 3-D conv127 (basic.py:16-30 with dims = 3, factory.py:15-17): LinearClassifier(BasicConv([7, 5, 5, 5, 5], dims=3)), BN +
+    PReLU, seeded, filled (dilations 1, 2, 4, 8, 16: receptive field 127^3), on a small tomogram.  A generator of its own so that
+    the fixtures of scoring3d_basic stay byte for byte what they were."""
+    from topaz.model.classifier import LinearClassifier
+    from topaz.model.features.basic import BasicConv
+    rs = np.random.RandomState(195)
+    torch.manual_seed(196)
+    m = LinearClassifier(BasicConv([7, 5, 5, 5, 5], 8, dims=3), dims=3)
+    randomise_bn(m, 197)
+    g = torch.Generator().manual_seed(198)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.PReLU):
+            mod.weight.data = 0.05 + 0.4 * torch.rand(mod.weight.shape, generator=g)
+    m.eval()
+    m.fill()
+    x = rs.randn(6, 9, 21).astype(np.float32)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x)[None, None])[0, 0].numpy()
+    save('score_conv127_3d_bn_u8', arch=np.asarray('conv127'), x0=x, y0=y, **sd_arrays(m))
+
+
 def extras():
     """rows the first round left partial: the radius search / validation of `topaz extract --targets`
     (extract.py:135-204,284-305), `topaz segment` score maps (model/utils.py:71-105), the inverse-Gaussian pre-filter.

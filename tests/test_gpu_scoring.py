@@ -296,11 +296,13 @@ def test_scoring_3d_patches_nms_and_user_pickle(gpu_ctx):
     assert np.array_equal(c, z['nms_coords']) and np.array_equal(s, z['nms_scores'])
 
 
-@pytest.mark.parametrize('name', ['conv31_3d_bn_u8', 'conv63_3d_bn_u8'])
+@pytest.mark.parametrize('name', ['conv31_3d_bn_u8', 'conv63_3d_bn_u8', 'conv127_3d_bn_u8'])
 def test_scoring_3d_basicconv_stacks_vs_reference_golden(gpu_ctx, name):
     """3-D BasicConv stacks (basic.py:12-111 with dims = 3: `-m conv31 --dims 3`): 7^3 stem, dilated 5^3 convs with folded
     eval-BN and per-layer PReLU slopes, fused 1x1x1 head -- against the reference's own output; conv31 also from its
-    full-module pickle; a 3-D conv127 is refused with a reason"""
+    full-module pickle.  conv127 (round 6; until then refused): its last 5^3 conv at dilation 16 reads 64 columns either side of
+    every row of every plane, too much for the LDS tiles of the 2xf16 kernels -- that one layer runs on a small-tile fp32-MFMA
+    instantiation (2 x 2 x 16 outputs per workgroup: slow, correct), the others where conv63's run"""
     import os
     from conftest import GOLDEN
     from topaz_amd.model.classifier import LinearClassifier
@@ -308,7 +310,7 @@ def test_scoring_3d_basicconv_stacks_vs_reference_golden(gpu_ctx, name):
     z = load_golden(f'score_{name}')
     arch = str(z['arch'])
     m = LinearClassifier(arch, golden_sd(z))
-    assert m.dims == 3 and m.width == {'conv31': 31, 'conv63': 63}[arch]
+    assert m.dims == 3 and m.width == {'conv31': 31, 'conv63': 63, 'conv127': 127}[arch]
     m.eval(); m.fill(); m.cuda()
     x = z['x0']
     y = m(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy()
@@ -320,9 +322,6 @@ def test_scoring_3d_basicconv_stacks_vs_reference_golden(gpu_ctx, name):
         assert m2.dims == 3
         m2.eval(); m2.fill(); m2.cuda()
         assert np.abs(m2(torch.from_numpy(x)[None, None].cuda())[0, 0].cpu().numpy() - z['y0']).max() <= ATOL
-        sd127 = dict(golden_sd(z))
-        with pytest.raises(NotImplementedError, match='conv127'):
-            LinearClassifier('conv127', sd127)
 
 
 # ---- ResNets with MaxPool layers: ResNet6 and `topaz train --pooling max` (resnet.py:10-47,254-339) ----------------------

@@ -31,7 +31,7 @@ def test_scoring_pretrained(name):
 
 
 @pytest.mark.parametrize('name', ['resnet8_bn_u16', 'resnet16_u16', 'conv127_bn_u16', 'conv31_u32', 'resnet8_3d_u8',
-                                  'resnet8_3d_bn_u8', 'resnet16_3d_u8', 'conv31_3d_bn_u8', 'conv63_3d_bn_u8'])
+                                  'resnet8_3d_bn_u8', 'resnet16_3d_u8', 'conv31_3d_bn_u8', 'conv63_3d_bn_u8', 'conv127_3d_bn_u8'])
 def test_scoring_seeded(name):
     z = load_golden(f'score_{name}')
     y = scoring.score(str(z['arch']), golden_sd(z), z['x0'])

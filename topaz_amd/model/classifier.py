@@ -41,10 +41,6 @@ class LinearClassifier:
         if dims not in (2, 3) or dims != wdims:
             raise ValueError(f'LinearClassifier: dims = {dims} with {wdims}-D weights')
         self.dims = dims
-        if dims == 3 and arch == 'conv127':
-            # (basic.py with dims = 3: the filled 5^3 conv at dilation 16 reads 64 columns either side of every row of every
-            # plane -- three LDS buffers of such tiles exceed a CU's 160 KB; conv31 / conv63 are the 3-D BasicConv stacks built)
-            raise NotImplementedError('3-D conv127 (receptive field 127^3) is not built: use conv31 / conv63 or a ResNet for 3-D picking')
         if arch in ('resnet6', 'resnet8', 'resnet16'):
             self._program, width = pack.pack_resnet(arch, self.state_dict_np, dims, self.pooling)
             units = self.state_dict_np['features.features.0.conv.weight'].shape[0]

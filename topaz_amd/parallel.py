@@ -8,6 +8,7 @@ One process per GPU; torch.distributed backend 'nccl' (= RCCL over xGMI on ROCm)
 from __future__ import annotations
 
 import os
+import sys
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -351,6 +352,9 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
     if not (dist.is_available() and dist.is_initialized()):
         return {int(i): (s.cpu(), c.cpu()) for i, s, c in zip(image_ids, scores, coords)}
     world, rank = dist.get_world_size(), dist.get_rank()      # (a 1-rank group takes the collective path too)
+    trace = os.environ.get('TOPAZ_AMD_TRACE_GATHER') == '1'   # per-phase host clock of this rank on stderr
+    import time as _time
+    marks = [('start', _time.perf_counter())]
     n_img = len(image_ids)
     counts = [int(s.numel()) for s in scores]                  # (shapes: host-side knowledge, no device read)
     n_rows = int(sum(counts))
@@ -358,6 +362,7 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
     metas_t = torch.zeros(world * 3, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(metas_t, meta)
     metas = metas_t.view(world, 3).cpu().tolist()              # the one host read
+    marks.append(('sizes all_gather', _time.perf_counter()))
     max_img = max(1, max(m[0] for m in metas))
     max_rows = max(1, max(m[1] for m in metas))
     d = max(m[2] for m in metas)
@@ -371,8 +376,13 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
         rows = buf[2 * max_img:2 * max_img + w * n_rows].view(n_rows, w)
         rows[:, :d] = torch.cat([c.to(device=device, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
         rows[:, d] = torch.cat([s.to(device=device, dtype=torch.float32).reshape(-1) for s in scores], 0).view(torch.int32)
+    marks.append(('pack', _time.perf_counter()))
     bufs = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, bufs, dst=dst)
+    marks.append(('gather', _time.perf_counter()))
+    if trace:
+        sys.stderr.write(f'[topaz_amd gather] rank {rank}: ' + ', '.join(f'{b[0]} {1e3 * (b[1] - a[1]):.1f} ms' for a, b in zip(marks, marks[1:]))
+                         + f' ({n_rows} rows of {n_img} images, buffer {buf.numel() * 4} B)\n')
     if rank != dst:
         return None
     out = {}
