@@ -29,7 +29,8 @@ def run(n: int, args) -> dict:
     if r.returncode != 0 or len(lines) != 1:
         return {'ranks': n, 'error': (r.stdout[-800:] + r.stderr[-1200:])}
     d = json.loads(lines[0])
-    return {'ranks': n, 'micrographs_per_s_all_ranks': d['value'], 'ms_per_step_per_rank': d['ms_per_step'],
+    trace = [l for l in r.stderr.splitlines() if l.startswith('[topaz_amd gather]')]      # (TOPAZ_AMD_TRACE_GATHER=1)
+    return {'ranks': n, **({'gather_trace': trace[-2 * n:]} if trace else {}), 'micrographs_per_s_all_ranks': d['value'], 'ms_per_step_per_rank': d['ms_per_step'],
             'rank_ms_per_step': d['rank_ms_per_step'], 'rank_host_cpu_ms_per_step': d['rank_host_cpu_ms_per_step'],
             'gather_ms': d['gather_ms'], 'images_total': d['config']['images_total'], 'rccl_world': d['rccl_world'],
             'picks_per_image': d['config']['picks_per_image']}

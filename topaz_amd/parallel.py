@@ -367,15 +367,20 @@ def gather_pick_tables(image_ids: Sequence[int], scores: Sequence[torch.Tensor],
     max_rows = max(1, max(m[1] for m in metas))
     d = max(m[2] for m in metas)
     w = d + 1
-    # one buffer per rank: [max_img x (id, n)] ++ [max_rows x (coords..., score bits)], int32
-    buf = torch.zeros(2 * max_img + w * max_rows, dtype=torch.int32, device=device)
+    # one buffer per rank: [max_img x (id, n)] ++ [max_rows x (coords..., score bits)], int32 -- packed WHERE THE TABLES LIVE
+    # (the rank's GPU) and moved to the collective's device in one piece: under gloo (host tensors) that is one device-to-host
+    # copy per rank instead of two per image
+    pdev = scores[0].device if n_img else device
+    buf = torch.zeros(2 * max_img + w * max_rows, dtype=torch.int32, device=pdev)
     if n_img:
         head = torch.tensor([[int(i), c] for i, c in zip(image_ids, counts)], dtype=torch.int32)
-        buf[:2 * n_img] = head.reshape(-1).to(device, non_blocking=True)
+        buf[:2 * n_img] = head.reshape(-1).to(pdev, non_blocking=True)
     if n_rows:
         rows = buf[2 * max_img:2 * max_img + w * n_rows].view(n_rows, w)
-        rows[:, :d] = torch.cat([c.to(device=device, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
-        rows[:, d] = torch.cat([s.to(device=device, dtype=torch.float32).reshape(-1) for s in scores], 0).view(torch.int32)
+        rows[:, :d] = torch.cat([c.to(device=pdev, dtype=torch.int32).reshape(-1, d) for c in coords], 0)
+        rows[:, d] = torch.cat([s.to(device=pdev, dtype=torch.float32).reshape(-1) for s in scores], 0).view(torch.int32)
+    if buf.device != device:
+        buf = buf.to(device)
     marks.append(('pack', _time.perf_counter()))
     bufs = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, bufs, dst=dst)
