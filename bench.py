@@ -458,9 +458,18 @@ def baseline_configs(ctx, models, imgs, args, dev, with_cpu):
         launches = ctx.launches() - l0
         _, _, fl = ctx.prof_get(0)
         ctx.prof_enable(False)
+        # board power and shader clock while the config runs back to back for ~0.5 s: which configs sit at the power cap
+        # (their time is their energy) and which leave power on the table (their time is stalls)
+        with GpuSampler(dev.index or 0) as gs:
+            t_end = time.perf_counter() + 0.5
+            while time.perf_counter() < t_end:
+                fn()
+            torch.cuda.synchronize(dev)
+        g = gs.summary()
         out[key] = {'ms': 1e3 * best, 'algorithmic_tflop': CONFIG_TFLOP[key], 'executed_tflop': fl / 1e12,
                     'executed_tflops': fl / best / 1e12, 'frac': fl / best / 1e12 / SPLIT_PEAK_TFLOPS,
-                    'reference_tflops': CONFIG_TFLOP[key] / best, 'conv_and_elementwise_launches': launches}
+                    'reference_tflops': CONFIG_TFLOP[key] / best, 'conv_and_elementwise_launches': launches,
+                    'power_w_mean': g['power_w_mean'], 'sclk_mhz_mean': g['sclk_mhz_mean']}
         return out[key]
 
     def scorer(m):

@@ -49,6 +49,10 @@ def main():
     for r in rows:
         if base and 'error' not in r:
             r['aggregate_vs_one_rank'] = r['micrographs_per_s_all_ranks'] / base['micrographs_per_s_all_ranks']
+            # ... and of the compute phase alone (each rank's own steps / its own compute time, summed): the exchange step here runs
+            # over gloo / TCP between processes that share one GPU and its NUMA node -- on the real node it is one RCCL gather
+            r['compute_aggregate_vs_one_rank'] = (sum(1e3 / v for v in r['rank_ms_per_step']['all']) /
+                                                  sum(1e3 / v for v in base['rank_ms_per_step']['all']))
     print(json.dumps({
         'what': f'bench.py --gpus N with every rank on GPU 0 (TOPAZ_AMD_SHARE_GPU=1, gloo), {args.size}^2 micrographs, '
                 f'-s {args.patch_size} -p {args.patch_padding}, {args.steps} steps per rank; aggregate_vs_one_rank = throughput summed '
