@@ -17,15 +17,22 @@ then the pick tables are gathered to rank 0 over RCCL (the only collective; time
 rank processes (topaz_amd.parallel.launch_local_ranks), one per GPU, and rank 0 prints the line.
 
 Prints ONE JSON line (see the driver contract) including
-  roofline     -- the dominant kernel class (conv_mfma, fp32 matrix cores): algorithmic FLOP / HIP-event
-                  time of those launches, measured live in a separate profiled step after the timed region
-  cpu_baseline -- the oracle (CPU restatement of the reference, torch-CPU) timed on a bounded sample of
-                  the same workload on this host, rank 0 and N=1 only (`--cpu-full`: one whole 4096^2 micrograph).
+  roofline     -- the dominant kernel (the conv instantiation with the most time in a step): algorithmic FLOP / HIP-event
+                  time of its launches in the timed steps themselves; class aggregates, HBM-bound rows and the sustained-MFMA
+                  probe from extra steps after the timed region
+  energy       -- the same roofline in joules: board power x time per micrograph against what the step's f16 MFMA FLOP cost
+                  at the probe's pJ / FLOP (the board runs the step at its power cap)
+  cpu_baseline -- the oracle (CPU restatement of the reference, torch-CPU) timed on a bounded sample of the same workload on
+                  one socket of this host, rank 0 and N=1 only (`--cpu-full`: one whole 4096^2 micrograph)
+  parity       -- the HIP path on the arrays of that cpu_baseline leg against the oracle's outputs: |denoised pixel| and
+                  |logit| deltas (bar 1e-4), device NMS on the oracle's logits (bar: identical picks); exit status 3 on failure
+  configs      -- BASELINE configs 2 / 3 / 5 and the detectors users run, one by one: ms, fraction of the 2xf16 peak, launches,
+                  board power and shader clock while the config runs back to back
   exact_fp32   -- the same step with every convolution pinned to the fp32-MFMA kernels (tpz_ctx_set_exact)
-  pcie_inclusive -- the same step fed from pinned host memory through the host-pointer entry points (H2D of the
-                  micrograph, D2H of the pick table, double-buffered), N=1 only.
-  full_patch_tensors -- the same step with the patch windows off (tpz_ctx_set_roi(0)): every layer of every denoise patch
-                  computes its whole tensor although only the patch centre is kept.  Same output, bit for bit.
+  leg_seconds  -- what each leg after the timed region cost (a default run takes well under a minute)
+`--extras` adds the secondary legs (minutes): pcie_inclusive (the step fed from pinned host memory), the A/B legs
+row_major_raster / patch_lanes_unbatched / full_patch_tensors, cli_inclusive (the CLI itself from MRC files on tmpfs) and a CPU
+baseline per config.
 `--dry-run` (CPU box, no GPU): skips the hot path and fabricates pick tables so that the launcher, the barriers and the
 gather can be exercised over gloo; its line carries "dry_run": true and is not a measurement.
 """

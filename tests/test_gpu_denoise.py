@@ -91,7 +91,7 @@ def test_user_trainable_archs_unet2_unet3_pickles(gpu_ctx, tag):
     z = load_golden(f'denoise2d_{tag}')
     with warnings.catch_warnings():
         # widths that are not multiples of 16 (nf = 12: sources of 12 + 12 and 24 + 1 channels) are loaded zero-padded to the
-        # next multiple (runtime.hip widen_program): every layer on the 2xf16 path, no mixed-program warning
+        # next multiple (rt_load.hip widen_program): every layer on the 2xf16 path, no mixed-program warning
         warnings.simplefilter('error')
         d = Denoise(os.path.join(GOLDEN, f'user_model_{tag}.sav'))
     n_conv, n_split, off = d.model.device_model.split_layers()
@@ -187,7 +187,7 @@ def test_full_size_tomogram_c5_tiles_vs_oracle(gpu_ctx):
 @pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'tight_padding'])
 def test_patch_windows_are_bit_identical(gpu_ctx, case, exact):
     """a patch keeps only its centre, so every layer computes only the rectangle the kept pixels depend on
-    (runtime.hip need_regions): the output must not change by one bit against computing every tensor in full --
+    (rt_exec.hip need_regions): the output must not change by one bit against computing every tensor in full --
     corner, edge and interior patches, odd sizes (pooled sizes not divisible by two), windows clipped at the borders,
     padding smaller than the receptive field (nothing to save: the windows must then cover everything).
     exact_fp32: the same on the fp32-MFMA / direct kernels (tpz_ctx_set_exact), whose launches take the same windows"""
@@ -289,7 +289,7 @@ def test_tomogram_tiles_sharded_like_ranks_would(gpu_ctx):
 
 
 def test_batch_is_cut_to_the_memory_it_may_take(gpu_ctx):
-    """every image of a batch has a workspace of its own (runtime.hip batch_that_fits): with no memory to spend the pass falls
+    """every image of a batch has a workspace of its own (rt_denoise.hip batch_that_fits): with no memory to spend the pass falls
     back to single patches on the lanes -- the launch count of tpz_ctx_set_batch(0), the same bits -- instead of failing"""
     from topaz_amd.denoise import Denoise
     d = Denoise('unet-small')
@@ -440,7 +440,7 @@ def test_batched_tiles_with_mixed_source_chunks(gpu_ctx, monkeypatch):
 
 @pytest.mark.parametrize('case', ['bench_net', 'pretrained', 'small', 'fcnn', 'ragged', 'unet3d'])
 def test_batched_patches_are_bit_identical(gpu_ctx, case):
-    """the same layer of up to 8 patches / tiles in ONE launch (conv_split_multi_kernel, runtime.hip rec_flush) against one
+    """the same layer of up to 8 patches / tiles in ONE launch (conv_split_multi_kernel, rt_core.hip rec_flush) against one
     patch at a time: identical bits -- patches of different sizes (corner / edge / interior), patch counts that do not fill
     the last batch, batch sizes 2, 3 and 8, windows on, the batches alternating on the two patch lanes (the default) and
     all on the ctx stream; the 3-D tiles through the plane-stacked modes"""
@@ -558,7 +558,7 @@ def test_unet_nf32_weights_resident_layers_with_windows_and_lanes(gpu_ctx):
 @pytest.mark.parametrize('nf', [20, 12, 40])
 def test_unet_of_any_width_runs_wholly_on_the_2xf16_path(gpu_ctx, nf):
     """UDenoiseNet (skip connections at every level: decoder sources of 2 nf + nf channels) with widths that are not multiples
-    of 16: loaded zero-padded (runtime.hip widen_program) -- every layer on the f16 matrix cores, whole image and patched,
+    of 16: loaded zero-padded (rt_load.hip widen_program) -- every layer on the f16 matrix cores, whole image and patched,
     within 1e-4 of the oracle, and equal to the exact-fp32 kernels within the same bound."""
     import warnings
     from topaz_amd.denoise import Denoise

@@ -128,7 +128,7 @@ def test_conv2d_fused_upsample_concat(gpu_ctx, shape):
 ])
 def test_conv2d_phase_upsample_concat(gpu_ctx, case):
     """conv(cat(upsample2x(h), skip)) computed per output parity on the low-resolution source with pre-summed
-    taps (runtime.hip prepare_phases / run_conv_phases) against the literal interpolate + cat + conv."""
+    taps (rt_load.hip prepare_phases / run_conv_phases) against the literal interpolate + cat + conv."""
     from topaz_amd import runtime as rt
     c1, (h1, w1), c2, cout, k = case
     H, W = 2 * h1, 2 * w1

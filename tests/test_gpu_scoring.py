@@ -252,7 +252,7 @@ def test_scoring_3d_wide_net_against_float64(gpu_ctx):
 def test_scoring_3d_volume_beyond_32bit_offsets_stays_on_fp32(gpu_ctx):
     """the plane-stacked 2xf16 kernels address one half of a split tensor with 32-bit byte offsets: a volume whose widest
     activation (128 channels = 16 cells here) would exceed 4 GiB per half -- more than 256^3 voxels -- is scored on the
-    fp32 kernels instead of failing (runtime.hip split_volume_fits); one voxel fewer per plane and it takes the 2xf16 path"""
+    fp32 kernels instead of failing (rt_forward.hip split_volume_fits); one voxel fewer per plane and it takes the 2xf16 path"""
     from topaz_amd.model.classifier import LinearClassifier
     from tools import synth_weights as sw
     sd = sw.calibrate_head(sw.resnet_sd_uncalibrated('resnet8', 32, 3, dims=3), (1.0, 0.0))

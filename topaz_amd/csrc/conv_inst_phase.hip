@@ -1,7 +1,7 @@
 // Kernels of the "phase" path: a convolution whose first source is an exactly 2x nearest-upsampled tensor
 // (U-Net decoders, denoising/models.py:140-171) is computed per output phase on the LOW-resolution source with
 // pre-summed weights (k = 3 -> 2 taps per axis, k = 5 -> 3 taps), written (plain) to the strided output positions; the skip-source part then runs
-// over the full-resolution grid and adds itself in place through the residual epilogue (runtime.hip, run_conv_phases).  K = 2 kernels, and the 1-channel skip-source stems.
+// over the full-resolution grid and adds itself in place through the residual epilogue (rt_exec.hip, run_conv_phases).  K = 2 kernels, and the 1-channel skip-source stems.
 #include "conv_registry.h"
 //              K  D  MT  TH  TW  KG RPS CIN1   EPI
 TPZ_CONV2D(2, 1, 32, 16, 32, 2, 2, false)

@@ -34,7 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgs {
     const float* in;          // [Cin1][D1][H1][W1] (strided)
     const float* in2;         // optional 2nd source: channels [Cin1, Cin) come from here (fused concat)
-    const float* wpk;         // packed weights (runtime.hip pack_weights)
+    const float* wpk;         // packed weights (rt_load.hip pack_weights)
     const float* bias;        // [Cout] or nullptr
     float* out;               // [Cout][Dout][Hout][Wout] (nullptr when the head is fused)
     const float* res;         // residual [Cout][Dres][Hres][Wres] or nullptr
@@ -58,7 +58,7 @@ struct ConvArgs {
     int pad_x, pad_y, pad_z;
     // Output lattice: element (oz, oy, ox) of the launch is stored at (oz*os + ooz, oy*os + ooy, ox*os + oox) of
     // a [Cout][Dfull][Hfull][Wfull] tensor (os = 1, offsets 0, full = out dims for an ordinary convolution;
-    // os = 2 for the phase launches of a conv over an exactly 2x nearest-upsampled source, see runtime.hip).
+    // os = 2 for the phase launches of a conv over an exactly 2x nearest-upsampled source, see rt_load.hip prepare_phases).
     int os, ooz, ooy, oox;
     int Dfull, Hfull, Wfull;
     int Dres, Hres, Wres, res_crop;

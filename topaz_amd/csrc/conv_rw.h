@@ -7,7 +7,7 @@
 // prologue and an epilogue as long as the loop itself -- 0.18 .. 0.22 of the f16 peak.  With 32 input channels the WHOLE K extent
 // fits the LDS at once, so here nothing is left of that machinery:
 //   * a persistent workgroup (one per CU, 4 waves) loads the layer's packed weights ONCE -- 9 steps x 4 KB = 36 KB, the same
-//     A-fragment lane order as conv_split (runtime.hip pack_weights_split with CC = 4: step s = tap s, lane group kb = cell kb) --
+//     A-fragment lane order as conv_split (rt_load.hip pack_weights_split with CC = 4: step s = tap s, lane group kb = cell kb) --
 //     and keeps them for every tile it computes;
 //   * an input tile is all 4 cells of (8 + 2) x (32 + 2 D) pixels, hi and lo planes: 45 .. 51 KB, double-buffered; the tile
 //     after the current one is fetched by buffer-addressed LDS-DMA (out-of-image cells zero-filled by the range check) while
@@ -105,6 +105,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
     const __amdgpu_buffer_rsrc_t srd_hi = make_srd(a.in, plane_bytes);
     const __amdgpu_buffer_rsrc_t srd_lo = make_srd(reinterpret_cast<const unsigned char*>(a.in) + plane_bytes, plane_bytes);
     unsigned rel[C::NR], pos[C::NR];
+    unsigned exists_mask = 0;              // bit r: piece r of this thread is a cell of the tile (not padding of the cell plane)
+    static_assert(C::NR <= 32, "exists_mask");
 #pragma unroll
     for (int r = 0; r < C::NR; ++r) {
         const int g = r * C::THREADS + tid;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
         const int rr = rem / C::ITW, xx = rem - rr * C::ITW;
         const bool exists = g < C::NPC && rem < C::ITH * C::ITW;
         rel[r] = (unsigned)(((size_t)c * a.Hin + (size_t)rr * D) * a.Win + xx) * 16u;
-        pos[r] = exists ? ((unsigned)(rr * D) << 16 | (unsigned)xx) : 0x7fff0000u;
+        pos[r] = (unsigned)(rr * D) << 16 | (unsigned)xx;
+        exists_mask |= exists ? 1u << r : 0u;       // (a predicate of its own: no sentinel position that a tall image could reach)
     }
     int y0, x0;
     auto set_tile = [&](unsigned L) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
         for (int r = 0; r < C::NR; ++r) {
             if ((r + 1) * C::THREADS <= C::NPC || r * C::THREADS + wave * 64 < C::NPC) {     // (whole waves of 1 KiB)
                 const int gy = ybase + (int)(pos[r] >> 16), gx = xbase + (int)(pos[r] & 0xffffu);
-                const bool in = (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+                const bool in = ((exists_mask >> r) & 1u) && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
                 const unsigned off = in ? rel[r] + base : OOB;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(C::OFF_IN + buf * C::IN_BUF + (r * C::THREADS + wave * 64) * 16));
                 bdma16(srd_hi, off, dst);

@@ -11,7 +11,7 @@
 // error and far inside the 1e-4 bar (tests/test_gpu_precision.py) -- not below it.  Weights are scaled per
 // output channel by a power of two before splitting (undone exactly in the epilogue) so that their lo
 // halves stay normal f16 numbers.  Activations beyond the f16 range raise a device flag; the runtime then
-// re-runs the forward pass on the fp32 kernels (runtime.hip).
+// re-runs the forward pass on the fp32 kernels (rt_forward.hip, rt_denoise.hip).
 //
 // GEMM view: M = output channels, N = output pixels, K = Cin * taps.  One MFMA covers 32 K-elements:
 //   lane (i, kb) holds 8 consecutive K values; kb = 0..3 selects a "slot" = (tap, 8-channel cell), the 8
@@ -53,9 +53,9 @@ struct SplitArgs {
     const uint4* in;          // split tensor: [2 planes][cells_in1][H1][W1] cells
     const uint4* in2;         // optional second source [2][cells_in - cells_in1][Hin][Win]: channels after those of
                               // `in`, which is then nearest-upsampled to Hin x Win (fused upsample + concat)
-    const uint4* wpk;         // packed weights (runtime.hip pack_weights_split)
+    const uint4* wpk;         // packed weights (rt_load.hip pack_weights_split)
     const float* wscale;      // [Cout] 2^-s: undoes the per-channel weight scaling.  This and the other per-channel vectors
-                              // are zero-padded to whole tiles (runtime.hip chan_pad): fetched as unclamped float4
+                              // are zero-padded to whole tiles (rt_internal.h chan_pad): fetched as unclamped float4
     const float* bias;        // [Cout] or nullptr
     uint4* out;               // split tensor [2][cells_out][Hfull][Wfull] (nullptr: fused head / fp32 output)
     float* out_f32;           // EPI_PLAIN_F32: fp32 planes [Cout][Hfull][Wfull] instead
@@ -79,7 +79,7 @@ struct SplitArgs {
     // geometry of `in` there (no upsampling).
     int KZ, pad_z, Din, Dout, ooz, Dfull, Dres;
     int ncz;                  // co-group slices of grid z: blockIdx.z = (plane * max(nphase, 1) + phase) * ncz + slice
-    // all output parities of a decoder conv in one launch (runtime.hip prepare_split_phases): phase p = (pz, py, px)
+    // all output parities of a decoder conv in one launch (rt_load.hip prepare_split_phases): phase p = (pz, py, px)
     // bits uses weights wpk + p * w_phase_bytes, scales wscale + p * Cout, pad (phase_k/2 - parity + 1)/2 and
     // lattice offset = parity on each axis (pad_* / oo* of the struct are then ignored)
     int nphase, phase_k, ws_phase_stride;
@@ -98,7 +98,7 @@ struct SplitArgs {
     int xcd_swizzle;
     // output WINDOW of the launch, in its own lattice coordinates: the tiles cover [wy0, wy1) x [wx0, wx1) only and nothing
     // outside it is stored (launch_split defaults it to the whole lattice).  A patch of a patched denoise keeps only its
-    // centre, so every layer computes only the part of its tensor that the kept pixels depend on (runtime.hip, need_regions).
+    // centre, so every layer computes only the part of its tensor that the kept pixels depend on (rt_exec.hip, need_regions).
     int wy0, wx0, wy1, wx1;
     // ... and, plane-stacked 3-D, the planes [wz0, wz0 + Dout) of the launch lattice (a tile of a tiled tomogram keeps its centre
     // in z as well).  Dlat: the lattice's full depth (host side only: the share of the layer's FLOP a windowed launch executes)
@@ -142,7 +142,7 @@ struct SplitSlot {
 };
 
 // K x KX taps (rows x columns; KX = K for the square kernels, KX = 1 for the column kernels that carry the x taps of
-// a stem as input channels or of a 1-output-channel conv as output channels, runtime.hip)
+// a stem as input channels or of a 1-output-channel conv as output channels, rt_load.hip prepare_split)
 template <int K_, int D_, int MT_, int TH_, int TW_, int CC_, int WAVES_ = 8, int KX_ = K_, int SPS_ = 1>
 struct SplitCfg {
     static constexpr int K = K_, KX = KX_, D = D_, MT = MT_, TH = TH_, TW = TW_, CC = CC_;
@@ -227,7 +227,7 @@ struct SplitPlanKey {
 };
 
 // Host: the schedule of one tile's K loop (SplitStep) for configuration C.  Entry 0 = the fetch of chunk 0 (all rounds, issued
-// in the prologue), entry 1 + s = step s.  Mirrors pack_weights_split (runtime.hip), which lays the weights out in the same
+// in the prologue), entry 1 + s = step s.  Mirrors pack_weights_split (rt_load.hip), which lays the weights out in the same
 // (step, lane group) -> (chunk, tap, cell) order.
 template <class C>
 void split_make_plan(const SplitPlanKey& k, std::vector<SplitStep>& out) {

@@ -1,5 +1,5 @@
 // 2xf16-split kernels of the 2-D U-Net denoisers at 48 base filters (topaz/denoising/models.py:74-175):
-// encoder / decoder 3x3 convs, the per-parity kernels of the decoders' first convs (runtime.hip
+// encoder / decoder 3x3 convs, the per-parity kernels of the decoders' first convs (rt_load.hip
 // prepare_phases: 2-tap kernels for k = 3, 3-tap for k = 5, added in place onto the skip-source part),
 // and dec1.2, whose consumer (the 1-channel last conv) reads fp32.
 #include "conv_split_registry.h"

@@ -8,7 +8,7 @@ TPZ_SPLIT(5, 4,  32, 16, 32, 2, ::tpz::EPI_HEAD)
 TPZ_SPLIT(5, 8,  32, 16, 32, 1, ::tpz::EPI_HEAD)
 TPZ_SPLIT(5, 16, 32, 16, 32, 1, ::tpz::EPI_HEAD)
 // ResNet heads at 32 and 64 units: 5x5 d4 64->128 (one co-group) is served by the MT = 128 head kernel of inst_a
-// column kernels (k x 1 taps, runtime.hip prepare_split): 1-channel stems with their kx taps as input channels
+// column kernels (k x 1 taps, rt_load.hip prepare_split): 1-channel stems with their kx taps as input channels
 // (7x7 / 7x7x7 / 11x11 at 32 / 48 / 64 outputs), 1-output-channel last convs with their kx taps as output channels
 //             K  D  MT  TH TW  CC  EPI
 TPZ_SPLIT4_COL(7,  1, 32, 8, 32, 1, ::tpz::EPI_PLAIN)

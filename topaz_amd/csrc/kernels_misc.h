@@ -37,7 +37,7 @@ hipError_t launch_to_split(const float* in, void* out, int C, int H, int W, unsi
 hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hipStream_t s);
 hipError_t launch_copy_box(const float* src, long long sps, int spitch, float* dst, long long dps, int dpitch, int bd,
                            int bh, int bw, hipStream_t s);
-// Range scaling of a scoring pass (runtime.hip tpz_model_forward): rng[0] = 2^-s, rng[1] = 0, rng[2] = 2^s, rng[3] = s with s >= 0
+// Range scaling of a scoring pass (rt_forward.hip tpz_model_forward): rng[0] = 2^-s, rng[1] = 0, rng[2] = 2^s, rng[3] = s with s >= 0
 // chosen from the exponent histogram of the image (its 99.9 % quantile of |x| brought to ~2^3); dst[i] = src[i] * 2^-s for the
 // model's bias-like vectors.  `hist` = 256 zeroed words (left zeroed).
 hipError_t launch_range_fit(const float* x, size_t n, unsigned* hist, float* rng, const float* src, float* dst, size_t n_vec,

@@ -625,7 +625,7 @@ hipError_t launch_from_split(const void* in, float* out, int C, int H, int W, hi
 // mode 1: E-step with the current parameters: log p_k = -(x-mu_k)^2/(2 var_k) - ln(2 pi var_k)/2 + ln(pi_k),
 //         Z = logsumexp, p_k = exp(log p_k - Z).
 // Accumulates, in fp64 and in a fixed order (deterministic), S = {sum Z, sum p0, sum p1, sum p0 x, sum p1 x,
-// sum p0 x^2, sum p1 x^2}: the M-step and the log-likelihood are closed forms of S (runtime.hip gmm_fit).
+// sum p0 x^2, sum p1 x^2}: the M-step and the log-likelihood are closed forms of S (rt_stats.hip gmm_fit).
 // par = {split | mu0, mu1, var0, var1, ln(1-pi), ln(pi)}.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gmm_pass_kernel(const float* __restrict__ x, size_t n, int mode,
@@ -680,13 +680,13 @@ hipError_t launch_gmm_pass(const float* x, size_t n, int mode, const double* d_p
 }
 
 // ------------------------------------------------------------------------------------------
-// Column-kernel helpers of the 2xf16 path (runtime.hip prepare_split).
+// Column-kernel helpers of the 2xf16 path (rt_load.hip prepare_split).
 // shiftx_split: out cell jc of pixel (z, y, x) = the 8 values x[z][y][x - pad + 8*jc + j], j = 0..7 (0 outside the
 // image or for taps >= K) as split f16 halves: the kx taps of a 1-channel stem become input channels.
 // shiftsum: out[z][y][x] = sum_v Y[v][z][y][x + v] + bias (then the un-normalisation): the kx taps of a
 // 1-output-channel conv were computed as K virtual output channels over W + 2*pad columns.
 // ------------------------------------------------------------------------------------------
-// (only rows [r0, r1) x columns [x0, x1) are produced: what the window of the stem conv reads, runtime.hip)
+// (only rows [r0, r1) x columns [x0, x1) are produced: what the window of the stem conv reads, rt_exec.hip)
 __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restrict__ in, uint4* __restrict__ out,
                                                            int ncell, int K, int pad, size_t rows, int W, int Wo,
                                                            unsigned* flag, size_t r0, size_t r1, int x0, int x1) {
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void shiftx_split_kernel(const float* __restri
 }
 
 // (only rows [y0, y1) x columns [x0, x1) of the planes [z0, z1) of Hp rows each are produced: the window of the layer,
-// runtime.hip; a 2-D tensor is one plane of `rows` rows)
+// rt_exec.hip; a 2-D tensor is one plane of `rows` rows)
 __global__ __launch_bounds__(256) void shiftsum_kernel(const float* __restrict__ Y, float* __restrict__ out, int K,
                                                        size_t rows, int W, int Wp, float bias,
                                                        const float* __restrict__ nrm, int norm_out, size_t y0, size_t y1,
@@ -942,7 +942,7 @@ hipError_t launch_conv_cout1_split(const void* in, const float* wt, float* out, 
 // space-to-depth of a 1-channel image / volume into one split cell per low-resolution pixel: channel
 // j = (2*qz + qy)*2 + qx of cell (z, y, x) is in[2z + qz][2y + qy][2x + qx] (2-D: qz = 0, channels 4..7 zero).  The
 // 1-channel skip source of a U-Net's dec1.0 joins the per-parity form of that layer as these extra input channels
-// (runtime.hip prepare_split_phases).
+// (rt_load.hip prepare_split_phases).
 __global__ __launch_bounds__(256) void s2d_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, int d, int h,
                                                         int w, int H, int W, int dims, unsigned* flag) {
     const size_t n = (size_t)d * h * w;

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void nms_write_kernel(const uint64_t* __restri
     }
 }
 
-// ---- host-side launch helpers (called from runtime.hip) -----------------------------------------
+// ---- host-side launch helpers (called from rt_nms.hip) -----------------------------------------
 static inline int nblocks(size_t n, int cap = 8192) {
     size_t b = (n + 255) / 256;
     if (b < 1) b = 1;

@@ -133,6 +133,9 @@ static int launch_rw(tpz_ctx* ctx, SplitArgs& a, int dil, int epi, double flops)
     a.n_tiles = (int)nt;
     if ((size_t)a.cells_in * a.Hin * a.Win * 16 >= ((size_t)1 << 32) - 16)
         return fail(ctx, "image too large for one launch (%d x %d): process it in patches", a.Hin, a.Win);
+    // (the residual plane is addressed with 32-bit offsets too, and with res_crop > 0 it is larger than the input plane)
+    if (a.res && (size_t)a.cells_out * a.Hres * a.Wres * 16 >= ((size_t)1 << 32) - 16)
+        return fail(ctx, "residual tensor too large for one launch (%d x %d): process the image in patches", a.Hres, a.Wres);
     const int wgs = std::max(8, ctx->n_cus / 8 * 8);
     const double wy = a.wy1 - a.wy0, wx = a.wx1 - a.wx0, span = 2.0 * dil;
     double bytes = (double)a.cells_in * 32.0 * std::min((double)a.Hin, wy + span) * std::min((double)a.Win, wx + span) +

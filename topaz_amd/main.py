@@ -49,8 +49,9 @@ def main(argv=None):
                 os.unlink(listfile)
     # like topaz/main.py:148 the command's return value (denoise returns its output paths) is NOT the exit status:
     # `raise SystemExit(<list>)` would print the list and exit 1 after a successful run
-    args.func(args)
-    return 0
+    # ... but an INT is a status: a command that reports failure by returning non-zero is not turned into a success
+    rc = args.func(args)
+    return rc if isinstance(rc, int) and not isinstance(rc, bool) else 0
 
 
 def _ranks_to_launch(args) -> int:
