@@ -154,9 +154,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
     const __amdgpu_buffer_rsrc_t srd_rh = make_srd(has_res ? (const void*)a.res : (const void*)a.out, has_res ? pl16_r : 16);
     const __amdgpu_buffer_rsrc_t srd_rl =
         make_srd(has_res ? (const void*)(reinterpret_cast<const unsigned char*>(a.res) + pl16_r) : (const void*)a.out, has_res ? pl16_r : 16);
-    // lane part: (second cell of the channel fragment) + (second half of the cell); fragment m adds 2 m cell planes
-    const unsigned lane_o = (unsigned)(l4 >> 1) * cp16_o + (unsigned)(l4 & 1) * 8u;
-    const unsigned lane_r = (unsigned)(l4 >> 1) * cp16_r + (unsigned)(l4 & 1) * 8u;
+    // (lane part of an access: (second cell of the channel fragment) cell planes; fragment m adds 2 m cell planes)
     const f32x2 slope2 = {a.slope, a.slope};
     bool big = false;
     int buf = 0;
@@ -167,26 +165,34 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
         // every wave's pieces of the current tile are in the LDS (each waited for its own behind its previous K loop) and every
         // wave is done reading the other buffer
         rw_barrier();
-        // per pixel fragment: output / residual offsets of this lane (window test folded into the offset)
-        unsigned ovo[NW], rvo[NW];
+        // per PAIR of pixel fragments (2q, 2q + 1: the two 16-pixel halves of tile row q of this wave): output / residual offsets of
+        // this lane (window test folded into the offset).  As in conv_split (round 6): a v_permlane16_swap per dword leaves the
+        // lanes of an even 16-lane row with both halves of their cell of fragment 2q's pixel and the lanes of an odd row with both
+        // halves of the same cell of fragment 2q + 1's pixel, so every store and every residual load is 16 bytes per lane -- half the
+        // memory instructions of the 8-byte form, every byte where it went before.
+        static_assert(NW % 2 == 0 && NFC == 2, "fragment pairs = the two halves of a tile row");
+        constexpr int NP = NW / 2;
+        unsigned ovw[NP], rvw[NP];
+        bool okp[NP];
 #pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            const int oy = cy0 + (wave * C::RPW + n / NFC) * D;
-            const int ox = cx0 + (n % NFC) * 16 + l15;
+        for (int q = 0; q < NP; ++q) {
+            const int oy = cy0 + (wave * C::RPW + q) * D;
+            const int ox = cx0 + (l4 & 1) * 16 + l15;
             const bool ok = oy < a.wy1 && ox < a.wx1;
             const int ry = oy < a.Hout ? oy : a.Hout - 1, rx = ox < a.Wout ? ox : a.Wout - 1;      // (clamped: loads stay in range)
-            ovo[n] = ok ? (unsigned)(oy * a.Wfull + ox) * 16u + lane_o : OOB;
-            rvo[n] = (unsigned)((ry + a.res_crop) * a.Wres + rx + a.res_crop) * 16u + lane_r;
+            okp[q] = ok;
+            ovw[q] = ok ? (unsigned)(oy * a.Wfull + ox) * 16u + (unsigned)(l4 >> 1) * cp16_o : OOB;
+            rvw[q] = (unsigned)((ry + a.res_crop) * a.Wres + rx + a.res_crop) * 16u + (unsigned)(l4 >> 1) * cp16_r;
         }
         // the residual cells of the tile are requested NOW and used behind the K loop: their latency hides under the MFMAs
-        u32x2 rh[MW][NW], rl[MW][NW];
+        u32x4 rch[MW][NP], rcl[MW][NP];
         if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) {
 #pragma unroll
             for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int n = 0; n < NW; ++n) {
-                    rh[m][n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rh, (int)(rvo[n] + 2u * m * cp16_r), 0, 0);
-                    rl[m][n] = __builtin_amdgcn_raw_buffer_load_b64(srd_rl, (int)(rvo[n] + 2u * m * cp16_r), 0, 0);
+                for (int q = 0; q < NP; ++q) {
+                    rch[m][q] = __builtin_amdgcn_raw_buffer_load_b128(srd_rh, (int)(rvw[q] + 2u * m * cp16_r), 0, 0);
+                    rcl[m][q] = __builtin_amdgcn_raw_buffer_load_b128(srd_rl, (int)(rvw[q] + 2u * m * cp16_r), 0, 0);
                 }
         }
         if (has_next) {
@@ -263,26 +269,46 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv_rw_kernel(const SplitArgs 
                 }
             }
 #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                f32x2 v[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x2 addend = bi[h];
-                    if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST)
-                        addend = add_halves(add_halves(addend, h ? rl[m][n].y : rl[m][n].x), h ? rh[m][n].y : rh[m][n].x);
-                    v[h] = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + addend;
-                    if constexpr (EPI == EPI_RES_POST) v[h] = v[h] * psc[h] + psh[h];
-                    v[h] = __builtin_elementwise_max(v[h], v[h] * slope2);
+            for (int q = 0; q < NP; ++q) {
+                // the residual cells of the pair -> half cells in accumulator layout (the swap is an involution)
+                u32x2 rh2[2] = {{0u, 0u}, {0u, 0u}}, rl2[2] = {{0u, 0u}, {0u, 0u}};
+                if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST) {
+                    const auto h0s = __builtin_amdgcn_permlane16_swap(rch[m][q][0], rch[m][q][2], false, false);
+                    const auto h1s = __builtin_amdgcn_permlane16_swap(rch[m][q][1], rch[m][q][3], false, false);
+                    const auto l0s = __builtin_amdgcn_permlane16_swap(rcl[m][q][0], rcl[m][q][2], false, false);
+                    const auto l1s = __builtin_amdgcn_permlane16_swap(rcl[m][q][1], rcl[m][q][3], false, false);
+                    rh2[0] = (u32x2){h0s[0], h1s[0]}; rh2[1] = (u32x2){h0s[1], h1s[1]};
+                    rl2[0] = (u32x2){l0s[0], l1s[0]}; rl2[1] = (u32x2){l0s[1], l1s[1]};
                 }
-                unsigned h0, l0, h1, l1;
-                split2m(v[0], h0, l0);
-                split2m(v[1], h1, l1);
-                const unsigned okmask = ovo[n] != OOB ? 0x7fff7fffu : 0u;
-                bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h0 & okmask));
-                bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, h1 & okmask));
-                const unsigned off = ovo[n] != OOB ? ovo[n] + 2u * m * cp16_o : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64((u32x2){h0, h1}, srd_oh, (int)off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64((u32x2){l0, l1}, srd_ol, (int)off, 0, 0);
+                unsigned hh[2][2], ll[2][2];          // [fragment of the pair][dword]
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = 2 * q + j;
+                    f32x2 v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 addend = bi[h];
+                        if constexpr (EPI == EPI_RES || EPI == EPI_RES_POST)
+                            addend = add_halves(add_halves(addend, h ? rl2[j].y : rl2[j].x), h ? rh2[j].y : rh2[j].x);
+                        v[h] = (f32x2){acc[m][n][2 * h], acc[m][n][2 * h + 1]} * sc[h] + addend;
+                        if constexpr (EPI == EPI_RES_POST) v[h] = v[h] * psc[h] + psh[h];
+                        v[h] = __builtin_elementwise_max(v[h], v[h] * slope2);
+                    }
+                    split2m(v[0], hh[j][0], ll[j][0]);
+                    split2m(v[1], hh[j][1], ll[j][1]);
+                }
+                // f16-range check on what is stored: after the swap a lane holds its OWN pixel's cell (fragment l4 & 1 of the pair)
+                const auto sh0 = __builtin_amdgcn_permlane16_swap(hh[0][0], hh[1][0], false, false);
+                const auto sh1 = __builtin_amdgcn_permlane16_swap(hh[0][1], hh[1][1], false, false);
+                const auto sl0 = __builtin_amdgcn_permlane16_swap(ll[0][0], ll[1][0], false, false);
+                const auto sl1 = __builtin_amdgcn_permlane16_swap(ll[0][1], ll[1][1], false, false);
+                const u32x4 chi = {sh0[0], sh1[0], sh0[1], sh1[1]}, clo = {sl0[0], sl1[0], sl0[1], sl1[1]};
+                const unsigned okmask = okp[q] ? 0x7fff7fffu : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bigacc = __builtin_elementwise_max(bigacc, __builtin_bit_cast(u16x2, chi[k] & okmask));
+                const unsigned off = okp[q] ? ovw[q] + 2u * m * cp16_o : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(chi, srd_oh, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(clo, srd_ol, (int)off, 0, 0);
             }
         }
         big = big || bigacc[0] >= 0x7c00 || bigacc[1] >= 0x7c00;
