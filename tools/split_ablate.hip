@@ -44,6 +44,7 @@ float run(const SplitArgs& a, dim3 grid, int iters) {
 }
 
 static bool g_lat = false, g_exp = false;
+static int g_issuer_half = 0;      // quick(): SplitArgs::issuer_half of the timed runs (the library sets 1 on the 8-wave MT >= 96 tiles)
 template <class C, int EPI>
 int bench(const char* name, int cin, int cout, int H) {
     const int span = C::D * (C::K - 1);
@@ -166,6 +167,7 @@ int quick(const char* name, int cin, int cout, int H) {
     a.os = 1; a.Hfull = Ho; a.Wfull = Ho; a.Hres = Ho; a.Wres = Ho; a.n_chunks = n_chunks; a.xcd_swizzle = 1;
     a.KZ = 1; a.Din = a.Dout = a.Dfull = a.Dres = 1;     // a 2-D launch, as launch_split fills it in
     a.wy0 = a.wx0 = 0; a.wy1 = Ho; a.wx1 = Ho;          // the whole lattice
+    a.issuer_half = (C::ISSUER_HALF && g_issuer_half) ? 1 : 0;
     a.cog_inner = EPI == EPI_HEAD ? n_cog : 1;
     a.tiles_x = (Ho + C::TW - 1) / C::TW;
     a.tiles_y = (Ho + C::TH * C::D - 1) / (C::TH * C::D) * C::D;
@@ -263,6 +265,16 @@ int main(int argc, char** argv) {
         bench<SplitCfg<3, 4, 64, 16, 32, 2, 8, 3, 2>, EPI_RES>("K3 D4 MT64 8w S=2 RES", 64, 64, 2048);
         bench<SplitCfg<3, 1, 96, 8, 32, 2, 4, 3, 1>, EPI_PLAIN>("K3 D1 MT96 4w (U-Net dec 96->96 at 1012^2)", 96, 96, 1014);
         bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
+        return 0;
+    }
+    if (argc > 1 && std::string(argv[1]) == "prio") {
+        // round 6: static issue priority for one half of the 8-wave workgroups during the K loop
+#define PRIO_AB(CFG, E, label, cin, cout, H) { for (int ih = 0; ih < 2; ++ih) { g_issuer_half = ih; printf("issuer_half %d\n", ih); \
+            quick<CFG, E>(label " [no priority]", cin, cout, H); quick<CFG, E, 524288>(label " [waves 4-7 prio 1]", cin, cout, H); \
+            quick<CFG, E, 1048576>(label " [waves 0-3 prio 1]", cin, cout, H); } g_issuer_half = 0; }
+        PRIO_AB(SplitCfg<3 TPZ_C 8 TPZ_C 128 TPZ_C 16 TPZ_C 32 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 1>, EPI_RES, "K3 D8 MT128 8w RES", 128, 128, 2048)
+        PRIO_AB(SplitCfg<3 TPZ_C 4 TPZ_C 128 TPZ_C 16 TPZ_C 32 TPZ_C 2 TPZ_C 8 TPZ_C 3 TPZ_C 2>, EPI_PLAIN, "K3 D4 MT128 8w S=2", 128, 128, 2048)
+        PRIO_AB(SplitCfg<5 TPZ_C 4 TPZ_C 128 TPZ_C 16 TPZ_C 32 TPZ_C 2 TPZ_C 8 TPZ_C 5 TPZ_C 1>, EPI_HEAD, "K5 D4 MT128 HEAD", 128, 256, 2048)
         return 0;
     }
     if (argc > 1 && std::string(argv[1]) == "epi") {

@@ -377,6 +377,7 @@ enum { EPI_PLAIN_F32 = 5, EPI_POOL = 6 };
 //   128 no per-step weight DMA   256 no per-step input DMA
 //   4096 input DMA without the offset table (contiguous dummy source)   8192 input DMA from a 2 MB window (always L2 hits)
 //   16384 DMA issued but never waited for inside the K loop (what the latency of a stage's own prefetch costs)
+//   524288 / 1048576 s_setprio 1 for the upper / lower half of an 8-wave workgroup during the K loop (experiment)
 //   262144 the round-5 epilogue accesses: 8-byte stores / residual loads per lane instead of the paired 16-byte ones
 //   2048 clock probe: every workgroup adds its duration in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
 //        to the two 64-bit counters behind a.flag -> effective clock of the variant (DVFS: the chip runs at its power limit)
@@ -758,6 +759,10 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
 
         unsigned long long probe_t1 = 0;
         if constexpr ((ABL & 2048) != 0) probe_t1 = __builtin_readcyclecounter();
+        // ABL 524288 / 1048576 (experiment): static issue priority for the second-dispatched half of an 8-wave workgroup -- the
+        // arbitration loser of every segment (MI355X_MICROARCH.md, two waves per SIMD, item 4) -- / for the first half
+        if constexpr ((ABL & 524288) != 0) { if (C::WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1); }
+        if constexpr ((ABL & 1048576) != 0) { if (C::WAVES == 8 && wave < 4) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll 1
         for (int s = 0; s < n_stages; ++s) {
             const int stage = s / C::SPS, sub = s - stage * C::SPS;      // (SPS = 1: stage = s, sub = 0)
@@ -913,6 +918,7 @@ __device__ __forceinline__ void conv_split_body(const SplitArgs& a, const unsign
             probe_pro += probe_t1 - probe_t0;
         }
 
+        if constexpr ((ABL & (524288 | 1048576)) != 0) __builtin_amdgcn_s_setprio(0);
         // ---- epilogue: un-scale, bias, residual, eval-BN affine, activation, (fused head), split store.
         // Channel-fragment (m) outer: the per-channel constants are fetched once per m, the residual cells of
         // all NW pixel fragments are requested back to back before the first is used (the memory latency is
