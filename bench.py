@@ -1011,6 +1011,14 @@ def main():
         t_leg = time.perf_counter()
         configs = baseline_configs(ctx, models, imgs, args, dev, with_cpu=args.extras and not args.no_cpu_baseline)
         leg_s['configs'] = time.perf_counter() - t_leg
+        if energy:
+            # the energy view per config: joules per unit at the config's own board power against what its executed f16 MFMA FLOP
+            # cost at the probe's pJ / FLOP (every layer of these configs is on the 2xf16 path: 3 MFMA FLOP per executed FLOP)
+            for c in configs.values():
+                if isinstance(c, dict) and c.get('power_w_mean') and c.get('executed_tflop'):
+                    j = c['power_w_mean'] * c['ms'] * 1e-3
+                    fl = 3.0 * c['executed_tflop'] * energy['probe_pj_per_f16_flop']
+                    c['joules'], c['mfma_floor_joules'], c['energy_frac'] = j, fl, fl / j if j > 0 else None
         if args.extras:
             t_leg = time.perf_counter()
             try:
