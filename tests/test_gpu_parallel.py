@@ -147,3 +147,38 @@ def test_bench_two_ranks_share_the_gpu(gpu_ctx):
     assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['config']['images_total'] == 4 and d['value'] > 0
     assert len(d['rank_ms_per_step']['all']) == 2 and d['config']['picks_per_image'] > 10
     assert d['roofline']['achieved'] > 0 and 'configs' not in d and 'cpu_baseline' not in d
+
+
+def test_bench_line_carries_parity_and_fails_on_a_broken_one(gpu_ctx):
+    """bench.py's own parity check: the default line carries `parity` -- the HIP path against the oracle on the
+    arrays of the cpu_baseline leg -- and `energy`, `leg_seconds`; the process exits 0 only when the bars hold.  The failing side is
+    checked on the function itself: a tampered oracle array makes `ok` false (bench.py then exits 3)."""
+    import argparse
+    import json
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '1', '--warmup', '1', '--size', '768', '--patch-size', '384',
+           '--patch-padding', '96', '--cpu-sample', '512', '--cpu-score-sample', '512', '--no-configs']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    p = d['parity']
+    assert p['ok'] and p['picks_equal'] and p['denoise_max_abs'] <= 1e-4 and p['logit_max_abs'] <= 1e-4 and p['picks'] > 50
+    assert d['cpu_baseline']['value'] > 0 and 'cpu_baseline' in d['leg_seconds'] and d['host_placement']['host_cpus_before_pinning']
+    assert 'cli_inclusive' not in d and 'pcie_inclusive' not in d                    # secondary legs: --extras only
+    # the failing side
+    sys.path.insert(0, root)
+    import torch
+    import bench
+    from oracle import nms as onms
+    from oracle import scoring as oscoring
+    models = bench.build_models('extract')
+    x = np.random.RandomState(5).randn(256, 256).astype(np.float32)
+    logit = oscoring.score('resnet8', models['score'][1], x)
+    args = argparse.Namespace(radius=14, threshold=-6.0)
+    keep = {'score_in': x, 'logit': logit, 'picks': onms.nms2d(logit, 14, -6.0)}
+    good = bench.parity_vs_oracle(models, keep, args, torch.device('cuda', 0))
+    assert good['ok'] and good['picks_equal'] and good['logit_max_abs'] <= 1e-4
+    bad = dict(keep, logit=logit + np.float32(3e-4))
+    out = bench.parity_vs_oracle(models, bad, args, torch.device('cuda', 0))
+    assert not out['ok'] and out['logit_max_abs'] > 1e-4
