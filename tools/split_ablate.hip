@@ -267,6 +267,17 @@ int main(int argc, char** argv) {
         bench<SplitCfg<5, 1, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D1 MT32 4w S=2 (dec1.2 64->32 at 2024^2)", 64, 32, 2028);
         return 0;
     }
+    if (argc > 1 && std::string(argv[1]) == "c127") {
+        // round 6: steps per stage on the 5x5 32 -> 32 tiles of conv127 that have a continuous slot stream (CC = 2: d2, d4)
+        quick<SplitCfg<5, 4, 32, 16, 32, 2, 8, 5, 1>, EPI_PLAIN>("K5 D4 MT32 8w 16x32 CC2 S=1 (current)", 32, 32, 2064);
+        quick<SplitCfg<5, 4, 32, 16, 32, 2, 8, 5, 2>, EPI_PLAIN>("K5 D4 MT32 8w 16x32 CC2 S=2", 32, 32, 2064);
+        quick<SplitCfg<5, 4, 32, 16, 32, 2, 8, 5, 4>, EPI_PLAIN>("K5 D4 MT32 8w 16x32 CC2 S=4", 32, 32, 2064);
+        quick<SplitCfg<5, 2, 32, 8, 32, 2, 4, 5, 1>, EPI_PLAIN>("K5 D2 MT32 4w 8x32 CC2 S=1 (current)", 32, 32, 2056);
+        quick<SplitCfg<5, 2, 32, 8, 32, 2, 4, 5, 2>, EPI_PLAIN>("K5 D2 MT32 4w 8x32 CC2 S=2", 32, 32, 2056);
+        quick<SplitCfg<5, 2, 32, 16, 32, 2, 8, 5, 1>, EPI_PLAIN>("K5 D2 MT32 8w 16x32 CC2 S=1", 32, 32, 2056);
+        quick<SplitCfg<5, 2, 32, 16, 32, 2, 8, 5, 4>, EPI_PLAIN>("K5 D2 MT32 8w 16x32 CC2 S=4", 32, 32, 2056);
+        return 0;
+    }
     if (argc > 1 && std::string(argv[1]) == "prio") {
         // round 6: static issue priority for one half of the 8-wave workgroups during the K loop
 #define PRIO_AB(CFG, E, label, cin, cout, H) { for (int ih = 0; ih < 2; ++ih) { g_issuer_half = ih; printf("issuer_half %d\n", ih); \

@@ -1,10 +1,15 @@
 #include "conv_split_registry.h"
 // conv127/63/31 (basic.py:47-63): 5x5 at dilations 2, 4, 8, 16, 32 units, the last one with the fused head
+// (round 6, tools/split_ablate c127, profiles/r06_c127_stages.txt: the d2 / d4 tiles -- the ones with a continuous slot stream,
+// CC = 2 -- with FOUR steps per stage, i.e. a workgroup barrier every fourth step, and d2 on the 8-wave 16 x 32 tile instead of the
+// 4-wave 8 x 32 one: persistent form 0.57 - 0.60 ms per 2048^2 layer against 0.63 - 0.68; the d8 / d16 tiles are CC = 1 -- their
+// input tile of two cells would not fit twice -- and keep one step per stage)
+//           K  D   MT  TH  TW  CC  S  EPI
+TPZ_SPLIT_S(5, 2,  32, 16, 32, 2, 4, ::tpz::EPI_PLAIN)
+TPZ_SPLIT_S(5, 4,  32, 16, 32, 2, 4, ::tpz::EPI_PLAIN)
 //         K  D   MT  TH  TW  CC  EPI
-TPZ_SPLIT4(5, 2, 32, 8, 32, 2, ::tpz::EPI_PLAIN)
-TPZ_SPLIT(5, 4,  32, 16, 32, 2, ::tpz::EPI_PLAIN)
 TPZ_SPLIT(5, 8,  32, 16, 32, 1, ::tpz::EPI_PLAIN)
-TPZ_SPLIT(5, 4,  32, 16, 32, 2, ::tpz::EPI_HEAD)
+TPZ_SPLIT_S(5, 4,  32, 16, 32, 2, 4, ::tpz::EPI_HEAD)
 TPZ_SPLIT(5, 8,  32, 16, 32, 1, ::tpz::EPI_HEAD)
 TPZ_SPLIT(5, 16, 32, 16, 32, 1, ::tpz::EPI_HEAD)
 // ResNet heads at 32 and 64 units: 5x5 d4 64->128 (one co-group) is served by the MT = 128 head kernel of inst_a
