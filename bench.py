@@ -671,6 +671,9 @@ def cli_inclusive(args, dev, n=16):
                 'input': 'N(0,1) noise over a jittered 36-px grid of dark Gaussian blobs (sigma 6, amplitude 2.5): particles for the '
                          'pretrained detector to find after denoising',
                 'io_mb_per_micrograph': {'read': 2 * mb, 'written': mb},
+                # file traffic this ONE rank sustains through both commands (eight ranks on a host ask for eight times this)
+                'io_mb_per_s': {'read': 2 * mb * n / (t2 - t0), 'written': mb * n / (t2 - t0),
+                                'denoise_job': 2 * mb * n / (t1 - t0), 'extract_job': mb * n / (t2 - t1)},
                 'where': d if base is None else 'tmpfs (/dev/shm)',
                 'note': 'topaz denoise -m unet-v0.2.1 -> topaz extract -m resnet8_u32 through topaz_amd.main in this process, model '
                         'loading included; MRC read + decode and MRC write overlapped with the GPU work by reader / writer threads'}
